@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MB/s of raw bytes encoded by the Unigram encode hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of Tokenizer::encode_ordinary_batch (reference
+src/tokenizer.rs:114-123 over src/model.rs:59-129) over one resident batch of
+synthetic text: BASELINE.json configs[1] — 32K vocab, 1 GB mixed code+Chinese
+corpus per GPU (weak scaling: every rank encodes its own shard, no data-path
+collective).  Inputs are already in HBM when the timed region starts; ids stay
+in HBM.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size-mb", type=int, default=1024, help="corpus bytes per GPU, in MiB")
+    ap.add_argument("--vocab", type=int, default=32000)
+    ap.add_argument("--max-token-length", type=int, default=16)
+    ap.add_argument("--kind", default="mixed", choices=["mixed", "ascii"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()  # no-op when the in-tree .so files are current
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+
+    import tokengeex_amd as tgx
+    from tokengeex_amd import synth
+
+    dev = local_rank
+    if tgx.device_count() <= dev:
+        raise SystemExit("bench.py needs a GPU (no usable HIP device); there is no CPU fallback")
+
+    # ---- workload: same vocabulary on every rank, a different corpus shard per rank
+    t0 = time.time()
+    vflat, _ = synth.make_corpus(4 << 20, args.kind, seed_offset=0)
+    toks, scores = synth.build_vocab(vflat[: 2 << 20], args.vocab, args.max_token_length)
+    flat, offs = synth.make_corpus(args.size_mb << 20, args.kind, seed_offset=1000 + rank)
+    n_bytes, n_samples = int(flat.size), int(offs.size - 1)
+    model = tgx.NativeModel(toks, scores, device=dev)
+    corpus = tgx.NativeCorpus(flat, offs, device=dev)
+    setup_s = time.time() - t0
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        res = model.encode_corpus(corpus)  # synchronous: returns when ids are complete in HBM
+        n_tok = res.num_tokens
+        res.free()
+        return n_tok
+
+    n_tokens = 0
+    for _ in range(args.warmup):
+        n_tokens = step()
+    kernel_ms: dict[str, float] = {}
+    sync_all()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        n_tokens = step()
+        for k, v in model.last_kernel_times().items():  # hipEvents on the model's stream
+            kernel_ms[k] = kernel_ms.get(k, 0.0) + v
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    alg_bytes = model.last_algorithmic_bytes()
+
+    tot_bytes, tot_tokens, max_elapsed = float(n_bytes), float(n_tokens), elapsed
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        max_elapsed = float(t.item())
+        s = torch.tensor([float(n_bytes), float(n_tokens)], dtype=torch.float64, device=f"cuda:{dev}")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        tot_bytes, tot_tokens = float(s[0].item()), float(s[1].item())
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        ms_per_step = max_elapsed / steps * 1e3
+        mb_s = tot_bytes * steps / max_elapsed / 1e6
+        dom = max(kernel_ms, key=kernel_ms.get) if kernel_ms else "encode_kernel"
+        dom_ms = kernel_ms.get(dom, 0.0) / steps
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        out = {
+            "metric": "MB/s raw bytes encoded (and tokens/s) at 32K/64K vocab, 1/2/4/8 GPUs",
+            "value": round(mb_s, 2),
+            "unit": "MB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"encode_ordinary_batch, {args.vocab} vocab (max token {args.max_token_length} B), "
+                            f"{args.size_mb} MiB {args.kind} corpus per GPU, ids bit-exact vs CPU oracle",
+                "bytes_per_gpu": n_bytes, "samples_per_gpu": n_samples, "tokens_per_gpu": int(n_tokens),
+                "parallelism": f"dp{world} (samples sharded, no collective)",
+            },
+            "mib_per_s": round(tot_bytes * steps / max_elapsed / 1048576.0, 2),
+            "tokens_per_s": round(tot_tokens * steps / max_elapsed, 1),
+            "kernel_ms_per_step": {k: round(v / steps, 3) for k, v in kernel_ms.items()},
+            "setup_s": round(setup_s, 1),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(toks, scores, flat, offs, model, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(toks, scores, flat, offs, model, target_seconds: float) -> dict:
+    """Times the CPU oracle ("port" of the reference's Rust path) on a bounded
+    prefix of the same corpus with all host cores, and checks the GPU ids
+    against it on that prefix (the parity gate of SURVEY.md §8d)."""
+    import numpy as np
+
+    from oracle import oracle as orc
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
+    ora = orc.OracleModel(toks, scores)
+    # calibrate on 8 MiB, then size the sample for ~target_seconds
+    k = int(np.searchsorted(offs, 8 << 20))
+    k = max(1, min(k, offs.size - 1))
+    t = time.perf_counter()
+    ora.encode_batch_flat(flat[: int(offs[k])], offs[: k + 1], threads=cores)
+    rate = float(offs[k]) / (time.perf_counter() - t)
+    want = int(min(float(flat.size), rate * target_seconds))
+    k = int(np.searchsorted(offs, want))
+    k = max(1, min(k, offs.size - 1))
+    sub_flat, sub_offs = flat[: int(offs[k])], offs[: k + 1]
+    t = time.perf_counter()
+    ids, oo = ora.encode_batch_flat(sub_flat, sub_offs, threads=cores)
+    dt = time.perf_counter() - t
+    res = model.encode_batch_flat(sub_flat, sub_offs)
+    same = bool(np.array_equal(res.offsets(), oo) and np.array_equal(res.ids(), ids))
+    res.free()
+    if not same:
+        raise SystemExit("PARITY FAILURE: GPU token ids differ from the CPU oracle on the baseline sample")
+    return {"value": round(float(sub_flat.size) / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+            "sample": f"first {k} samples ({sub_flat.size} bytes) of the same corpus, {cores} threads, "
+                      f"{dt:.1f} s; GPU ids on this sample bit-exact: {same}",
+            "tokens_per_s": round(float(ids.size) / dt, 1)}
+
+
+if __name__ == "__main__":
+    main()

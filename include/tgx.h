@@ -1,0 +1,185 @@
+/*
+ * tgx.h — C ABI of the MI355X-native TokenGeeX Unigram encode / E-step path.
+ *
+ * This is the drop-in boundary: a Rust `extern "C"` block, a
+ * C++ host or Python/ctypes bind exactly these symbols.  Plain pointers and
+ * sizes only; no exceptions or unwinding cross it; every function returns a
+ * tgx_status.  All reference citations are relative to /root/reference.
+ *
+ * Batch format (replaces Vec<&str> / &[&str] of the reference's batch loops):
+ *   text  : uint8_t[N]      all samples' bytes back to back (already processed
+ *                           by the tokenizer's processors, as in cli.rs:276-287)
+ *   offs  : uint64_t[S+1]   sample i = text[offs[i] .. offs[i+1])
+ * Result format (replaces Vec<Vec<u32>>):
+ *   ids   : uint32_t[T]     token ids of all samples back to back
+ *   ooffs : uint64_t[S+1]   sample i's ids = ids[ooffs[i] .. ooffs[i+1])
+ *
+ * The library fails loudly (TGX_ERR_DEVICE) when no gfx950 device is usable;
+ * there is no CPU fallback behind these entry points.
+ */
+#ifndef TGX_H
+#define TGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGX_ABI_VERSION 1
+
+/* tokengeex::Error — src/lib.rs:219-224 (+ build-specific codes >= 5) */
+typedef enum tgx_status {
+    TGX_OK = 0,
+    TGX_ERR_IO = 1,                 /* Error::IO                                   */
+    TGX_ERR_JSON = 2,               /* Error::SerdeJSON                            */
+    TGX_ERR_TOKEN_ID_OOB = 3,       /* Error::TokenIdOutOfBounds(id)               */
+    TGX_ERR_NO_PATH = 4,            /* Error::NoPath(pos, len), src/model.rs:119   */
+    TGX_ERR_DEVICE = 5,             /* HIP runtime / no GPU / kernel failure       */
+    TGX_ERR_Z_NOT_NORMAL = 6,       /* the panic at src/prune.rs:90-96             */
+    TGX_ERR_INVALID = 7,            /* bad argument                                */
+    TGX_ERR_UNSUPPORTED = 8         /* e.g. a token longer than TGX_MAX_TOKEN_LEN  */
+} tgx_status;
+
+/* Longest vocabulary token (bytes) the device lattice handles.  The reference's
+ * recipes use 16 (README.md:161) to 24 (cli.rs:723). */
+#define TGX_MAX_TOKEN_LEN 64
+
+/* E-step snippet length: const MAX_SAMPLE_LENGTH = 8192 * 10, src/prune.rs:75 */
+#define TGX_ESTEP_SNIPPET_LEN 81920
+
+typedef struct tgx_model tgx_model;   /* Model: vocab + trie, src/model.rs:8-12   */
+typedef struct tgx_corpus tgx_corpus; /* a packed batch resident in HBM            */
+typedef struct tgx_result tgx_result; /* ids + offsets of one encode pass          */
+
+/* ---- error reporting ----------------------------------------------------- */
+/* Message of the last failure on the calling thread, formatted like the
+ * reference's Display impl (src/lib.rs:238-249), e.g.
+ * "no path to position 12/12", "token id 7 is out of bounds". */
+const char *tgx_last_error(void);
+/* Details of the last TGX_ERR_NO_PATH / TGX_ERR_Z_NOT_NORMAL: the LOWEST failing
+ * sample index (the reference leaves it unspecified, src/tokenizer.rs:107-110),
+ * and (pos, len) of Error::NoPath. */
+void tgx_last_error_detail(uint64_t *sample, uint64_t *pos, uint64_t *len);
+int tgx_abi_version(void);
+/* Number of usable gfx950 devices (0 when none; never fails). */
+int tgx_device_count(void);
+
+/* ---- Model ---------------------------------------------------------------- */
+/* Model::from(vocab) — src/model.rs:16-30.  Token i = bytes[offs[i]..offs[i+1]),
+ * id = i, scores[i] = vocab[i].score passed as raw f64 (never re-parsed).
+ * Later duplicates overwrite earlier ones (src/trie.rs:19); empty tokens never
+ * match (src/trie.rs:53-61).  Flattens the byte trie into an XOR double-array in
+ * HBM on `device`.  The handle is immutable and may be used concurrently; mutation
+ * = build a new handle (as `*model = Model::from(vocab)`, src/prune.rs:48,53). */
+tgx_status tgx_model_create(const uint8_t *bytes, const uint64_t *offs, const double *scores,
+                            uint32_t vocab_size, int device, tgx_model **out);
+void tgx_model_destroy(tgx_model *m);
+uint32_t tgx_model_vocab_size(const tgx_model *m);     /* Model::vocab_size, src/model.rs:179 */
+uint32_t tgx_model_max_token_len(const tgx_model *m);
+uint64_t tgx_model_trie_bytes(const tgx_model *m);     /* size of the device table */
+int tgx_model_device(const tgx_model *m);
+
+/* Model::common_prefix_search — src/model.rs:132-138 / src/trie.rs:44-64 (host
+ * twin of the device walk over the same flattened table).  Writes up to cap
+ * (id, len) pairs in ascending length; *count = number found. */
+tgx_status tgx_common_prefix_search(const tgx_model *m, const uint8_t *s, uint64_t n,
+                                    uint32_t *ids, uint32_t *lens, uint64_t cap, uint64_t *count);
+
+/* ---- host-only trie introspection (no device needed) ------------------------
+ * The same flattening tgx_model_create uploads, built on the host alone, so that
+ * the layout can be validated (and inspected) on machines without a GPU. */
+typedef struct tgx_flat_trie tgx_flat_trie;
+tgx_status tgx_flat_trie_build(const uint8_t *bytes, const uint64_t *offs, const double *scores,
+                               uint32_t vocab_size, tgx_flat_trie **out);
+void tgx_flat_trie_free(tgx_flat_trie *t);
+/* as tgx_common_prefix_search; returns the number of matches */
+uint64_t tgx_flat_trie_search(const tgx_flat_trie *t, const uint8_t *s, uint64_t n, uint32_t *ids,
+                              uint32_t *lens, uint64_t cap);
+void tgx_flat_trie_stats(const tgx_flat_trie *t, uint64_t *n_slots, uint64_t *n_nodes,
+                         uint32_t *max_token_len);
+/* out-of-line copy of tgx_dropout_u01 (below) for bindings that cannot inline C */
+double tgx_dropout_u01_host(uint64_t seed, uint64_t sample, uint64_t pos, uint32_t len);
+
+/* ---- encode: Tokenizer::encode_ordinary_batch / the rayon loop ----------- */
+/* src/tokenizer.rs:102-123 over src/model.rs:59-129.  Host buffers in, result
+ * handle out (host-readable).  dropout/seed: see tgx_dropout_u01.  On
+ * TGX_ERR_NO_PATH *out is NULL and tgx_last_error_detail names the sample. */
+tgx_status tgx_encode_batch(tgx_model *m, const uint8_t *text, const uint64_t *offs,
+                            uint64_t n_samples, double dropout, uint64_t seed, tgx_result **out);
+
+uint64_t tgx_result_num_samples(const tgx_result *r);
+uint64_t tgx_result_num_tokens(const tgx_result *r);
+/* Host pointers (copied from the device on first use); valid until tgx_result_free. */
+const uint32_t *tgx_result_ids(tgx_result *r);
+const uint64_t *tgx_result_offsets(tgx_result *r);
+/* Device pointers of the same arrays (for callers that keep ids in HBM). */
+const void *tgx_result_ids_device(const tgx_result *r);
+const void *tgx_result_offsets_device(const tgx_result *r);
+void tgx_result_free(tgx_result *r);
+
+/* ---- resident corpus: the prune / merge training loops -------------------- */
+/* The reference holds `samples: &[&str]` in RAM across all EM / merge passes
+ * (src/prune.rs:23, src/merge.rs:33); here the batch is uploaded once and stays
+ * in HBM while models change.  Samples are processed longest-first. */
+tgx_status tgx_corpus_upload(int device, const uint8_t *text, const uint64_t *offs,
+                             uint64_t n_samples, tgx_corpus **out);
+void tgx_corpus_free(tgx_corpus *c);
+uint64_t tgx_corpus_num_samples(const tgx_corpus *c);
+uint64_t tgx_corpus_num_bytes(const tgx_corpus *c);
+
+/* Model::encode over every sample of the corpus; result stays in HBM until the
+ * host pointers are asked for. */
+tgx_status tgx_encode_corpus(tgx_model *m, tgx_corpus *c, double dropout, uint64_t seed,
+                             tgx_result **out);
+
+/* Frequency pass of prune_vocab — src/prune.rs:205-244: freq[id] += 1 for every
+ * Viterbi token (dropout 0.0).  freq[vocab_size] is ACCUMULATED into (host). */
+tgx_status tgx_count_tokens(tgx_model *m, tgx_corpus *c, uint64_t *freq);
+
+/* Pair scan of merge — src/merge.rs:53-76: adjacent id pairs inside each sample.
+ * Returns malloc'd arrays sorted by key = (a << 32) | b; free with tgx_free. */
+tgx_status tgx_count_pairs(tgx_model *m, tgx_corpus *c, uint64_t **keys, uint64_t **counts,
+                           uint64_t *n_pairs);
+
+/* run_e_step — src/prune.rs:64-120 over src/model.rs:34-55 + src/lattice.rs:245-333:
+ * each sample cut into <= snippet_len-byte snippets, forward/backward in f64
+ * log-space, expected[vocab_size] ACCUMULATED into (host), *logz_sum = sum of z.
+ * TGX_ERR_Z_NOT_NORMAL where the reference would panic (expected[] is still
+ * filled). */
+tgx_status tgx_estep(tgx_model *m, tgx_corpus *c, uint64_t snippet_len, double dropout,
+                     uint64_t seed, double *expected, double *logz_sum);
+
+void tgx_free(void *p);
+
+/* ---- measurement ---------------------------------------------------------- */
+/* Per-kernel GPU time of the last pass on this model's stream, measured with
+ * hipEvents recorded on that stream around each launch.  names[i] are static
+ * strings.  Returns the number of kernels written (<= cap). */
+int tgx_last_kernel_times(const tgx_model *m, const char **names, float *ms, int cap);
+/* Algorithmic bytes of the last pass, SURVEY.md §8(d): encode N + 4T + 16(S+1). */
+uint64_t tgx_last_algorithmic_bytes(const tgx_model *m);
+
+/* ---- dropout ---------------------------------------------------------------
+ * The reference draws rand::random::<f64>() from an unseeded thread RNG
+ * (src/model.rs:48,100), so dropout > 0 is not reproducible there.  This build
+ * replaces it with a counter hash of (seed, sample index, byte position, token
+ * length) so that runs are reproducible and the CPU oracle and the HIP kernels
+ * make identical decisions.  encode keeps a multi-byte match iff dropout < u
+ * (model.rs:100); populate_nodes skips it iff u < dropout (model.rs:48). */
+static inline double tgx_dropout_u01(uint64_t seed, uint64_t sample, uint64_t pos, uint32_t len) {
+    uint64_t x = seed ^ (sample * 0x9E3779B97F4A7C15ULL) ^ (pos * 0xC2B2AE3D27D4EB4FULL) ^
+                 ((uint64_t)len * 0x165667B19E3779F9ULL);
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGX_H */

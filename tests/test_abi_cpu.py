@@ -1,0 +1,141 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol declared in
+include/tgx.h, fails loudly without a GPU, and the host glue mirrors the
+reference's Tokenizer semantics."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+import tokengeex_amd as tgx
+from tokengeex_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "tgx.h"), encoding="utf-8") as f:
+        hdr = f.read()
+    declared = set(re.findall(r"\b(tgx_[a-z_0-9]+)\s*\(", hdr)) - {"tgx_dropout_u01"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert getattr(so, name) is not None
+    assert so.tgx_abi_version() == 1
+
+
+def test_fails_loudly_without_gpu():
+    if tgx.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(tgx.TokenGeeXError) as e:
+        tgx.NativeModel([b"a"], [0.0])
+    assert e.value.status == _lib.ERR_DEVICE
+    tk = tgx.Tokenizer([(b"a", -1.0, False)])
+    with pytest.raises(tgx.TokenGeeXError):
+        tk.encode("a", 0.0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "tokengeex_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", ".c")):
+                with open(os.path.join(dirpath, fn), encoding="utf-8") as f:
+                    src = f.read()
+                assert "oracle" not in src.replace("CPU oracle", "").replace("the oracle", ""), fn
+
+
+def test_dropout_hash_matches_oracle():
+    from oracle import oracle as orc
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        a = [int(x) for x in rng.integers(0, 2**63, size=3)]
+        l = int(rng.integers(1, 65))
+        assert _lib.dropout_u01(a[0], a[1], a[2], l) == orc.dropout_u01(a[0], a[1], a[2], l)
+
+
+def test_flat_trie_matches_oracle_prefix_search():
+    """The XOR double-array (host twin of the device walk) against the oracle's
+    hash-map trie on every suffix of real text, incl. duplicates and empty tokens."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(11)
+    flat, _ = synth.make_corpus(128 << 10, "mixed")
+    text = bytes(flat)
+    for n_multi, max_len in [(50, 4), (3000, 16), (20000, 24), (500, 64)]:
+        toks, scores = synth.random_vocab(rng, text, n_multi, max_len)
+        toks = toks + [toks[5], b"", toks[17]]  # duplicates + empty token
+        scores = np.concatenate([scores, [-1.0, -2.0, -3.0]])
+        ft = _lib.FlatTrie(toks, scores)
+        ora = orc.OracleModel(toks, scores)
+        assert ft.max_token_len == max(len(t) for t in toks)
+        for _ in range(3000):
+            i = int(rng.integers(0, len(text) - 1))
+            s = text[i:i + 80]
+            assert ft.common_prefix_search(s) == ora.common_prefix_search(s)
+        st = ft.stats()
+        assert st["n_slots"] % 256 == 0 and st["fill"] > 0.5, st
+
+
+def test_flat_trie_large_vocab_builds_fast():
+    flat, _ = synth.make_corpus(8 << 20, "mixed")
+    toks, scores = synth.build_vocab(flat[: 4 << 20], 200000, 16)
+    import time
+    t = time.time()
+    ft = _lib.FlatTrie(toks, scores)
+    dt = time.time() - t
+    st = ft.stats()
+    assert dt < 20.0, dt
+    assert st["fill"] > 0.6, st
+
+
+def test_special_splitter_kats(golden_dir):
+    import json
+    with open(os.path.join(golden_dir, "reference_kats.json"), encoding="utf-8") as f:
+        kats = json.load(f)
+    for c in kats["splitter"]["cases"]:
+        assert tgx.split_special_tokens(c["input"], c["specials"]) == [(s, b) for s, b in c["segments"]]
+    # first-listed special wins at one position, not the longest (src/tokenizer.rs:325-338)
+    assert tgx.split_special_tokens("<EOS_2>", ["<EOS", "<EOS_2>"]) == [("<EOS", True), ("_2>", False)]
+
+
+def test_splitter_matches_oracle_on_random_inputs():
+    from oracle import oracle as orc
+    rng = np.random.default_rng(2)
+    specials = ["<EOS>", "ab", "<EOS_2>", "你", "b"]
+    alphabet = ["a", "b", "<", "EOS", ">", "_2", "你", "好", " ", "<EOS>"]
+    for _ in range(300):
+        s = "".join(alphabet[int(j)] for j in rng.integers(0, len(alphabet), size=int(rng.integers(0, 30))))
+        want = orc.split_specials(s.encode(), [x.encode() for x in specials])
+        assert [(a.encode(), b) for a, b in tgx.split_special_tokens(s, specials)] == want
+
+
+def test_tokenizer_json_roundtrip_and_queries(tmp_path):
+    vocab = [(b"a", -1.0, True), (b"\xff\xfe", -2.5, False), ("你好".encode(), -3.0, False), (b"a", -9.0, False)]
+    tk = tgx.Tokenizer(vocab, [tgx.CrlfProcessor(), tgx.UnicodeProcessor("nfc")], ["<EOS>", "<PAD>", "<EOS>"])
+    assert tk.special_tokens() == ["<EOS>", "<PAD>"]
+    assert (tk.vocab_size(), tk.base_vocab_size(), tk.special_vocab_size()) == (6, 4, 2)
+    assert tk.base_token_to_id(b"a") == 3  # later duplicate wins (src/model.rs:21)
+    assert tk.token_to_id(b"<PAD>") == 5 and tk.special_token_to_id("<EOS>") == 4
+    assert tk.id_to_token(1) == b"\xff\xfe" and tk.id_to_token(4) == b"<EOS>" and tk.id_to_token(9) is None
+    assert tk.id_to_base_token(2) == ("你好".encode(), -3.0)
+    assert tk.is_special(4) and not tk.is_special(3) and tk.is_base(3) and not tk.is_special(99)
+    assert tk.decode([0, 2, 4, 1], True) == "a你好<EOS>��"
+    assert tk.decode([0, 2, 4, 1], False) == "a你好��"
+    with pytest.raises(tgx.TokenGeeXError) as e:
+        tk.decode([77], True)
+    assert str(e.value) == "token id 77 is out of bounds"
+    p = tmp_path / "tok.json"
+    tk.save(str(p))
+    tk2 = tgx.Tokenizer.from_file(str(p))
+    assert tk2.to_string() == tk.to_string()
+    assert '"encoded":true' in tk.to_string() and '"keep":true' in tk.to_string()
+    tk3 = pickle.loads(pickle.dumps(tk))
+    assert tk3.vocab() == tk.vocab() and tk3.special_tokens() == tk.special_tokens()
+    with pytest.raises(tgx.TokenGeeXError):
+        tgx.Tokenizer.from_str('{"version":"1.0","vocab":[]}')
+    with pytest.raises(tgx.TokenGeeXError):
+        tgx.Tokenizer.from_str('{"version":"2.0","vocab":[],"bogus":1}')
+    with pytest.raises(tgx.TokenGeeXError):
+        tgx.Tokenizer.from_file(str(tmp_path / "missing.json"))

@@ -1,0 +1,174 @@
+"""GPU parity: the HIP encode path (through the C ABI) must produce token ids
+bit-identical to the CPU oracle on the same inputs."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import tokengeex_amd as tgx
+from oracle import oracle as orc
+from tokengeex_amd import synth
+
+from util import assert_same_encoding, corpus_and_vocab
+
+
+def _pair(tokens, scores):
+    return tgx.NativeModel(tokens, scores), orc.OracleModel(tokens, scores)
+
+
+def _enc(native, texts, dropout=0.0, seed=0):
+    flat, offs = tgx.pack(texts)
+    res = native.encode_batch_flat(flat, offs, dropout, seed)
+    ids, oo = res.ids(), res.offsets()
+    return [ids[int(oo[i]):int(oo[i + 1])].tolist() for i in range(len(texts))]
+
+
+def test_reference_kats_on_gpu(golden_dir):
+    with open(os.path.join(golden_dir, "reference_kats.json"), encoding="utf-8") as f:
+        kats = json.load(f)
+    for k in kats["encode"]:
+        nat = tgx.NativeModel([t.encode() for t, _ in k["vocab"]], [s for _, s in k["vocab"]])
+        assert _enc(nat, [k["input"].encode()], k["dropout"], seed=99) == [k["ids"]], k["source"]
+    k = kats["default_vocab_roundtrip"]
+    toks = [bytes([i]) for i in range(256)]
+    nat = tgx.NativeModel(toks, [1.0 / 256.0] * 256)
+    raw = k["input"].encode("utf-8")
+    assert _enc(nat, [raw]) == [list(raw)]
+
+
+def test_hf_golden_on_gpu(golden_dir):
+    with open(os.path.join(golden_dir, "hf_ascii.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    for case in g["cases"]:
+        nat = tgx.NativeModel([t.encode() for t, _ in case["vocab"]], [s for _, s in case["vocab"]])
+        got = _enc(nat, [t.encode("ascii") for t in case["texts"]])
+        assert got == case["ids"]
+
+
+def test_edge_cases():
+    nat, ora = _pair([b"a", b"b", b"ab", b"", b"ab"], [-3.0, -3.0, -6.0, -1.0, -6.0])
+    texts = [b"", b"a", b"ab", b"abab", b"", b"b" * 63, b"a" * 64, b"ab" * 32 + b"a", b"a" * 65, b"ab" * 64, b"b" * 129]
+    assert _enc(nat, texts) == ora.encode_batch(texts)
+    # ties: longest token wins; duplicate bytes: last id wins (id 4, never 2)
+    assert _enc(nat, [b"ab"]) == [[4]]
+    assert nat.common_prefix_search(b"abz") == ora.common_prefix_search(b"abz") == [(0, 1), (4, 2)]
+
+
+def test_no_path_reports_lowest_sample():
+    nat, _ = _pair([b"a", b"b"], [-1.0, -1.0])
+    flat, offs = tgx.pack([b"ab", b"abc", b"a", b"!!", b""])
+    with pytest.raises(tgx.TokenGeeXError) as e:
+        nat.encode_batch_flat(flat, offs)
+    assert str(e.value) == "no path to position 3/3"  # src/lib.rs:243-245
+    assert (e.value.status, e.value.sample, e.value.pos, e.value.length) == (4, 1, 3, 3)
+    # the handle stays usable after an error
+    assert _enc(nat, [b"abba"]) == [[0, 1, 1, 0]]
+
+
+def test_positive_scores_and_invalid_utf8_tokens():
+    toks = [bytes([i]) for i in range(256)] + [b"\xff\xfe", b"\xe4\xb8", b"\x80\x80\x80"]
+    scores = [1.0 / 256.0] * 256 + [5.0, 0.25, -1.0]
+    nat, ora = _pair(toks, scores)
+    rng = np.random.default_rng(3)
+    texts = [bytes(rng.integers(0, 256, size=int(n)).astype(np.uint8)) for n in [1, 5, 64, 100, 1000]]
+    texts += [b"\xff\xfe" * 40, "你好，我叫罗杰斯".encode()]
+    assert _enc(nat, texts) == ora.encode_batch(texts)
+
+
+@pytest.mark.parametrize("max_len", [2, 3, 7, 16, 17, 24, 33, 64])
+def test_random_vocab_parity_across_token_lengths(max_len):
+    rng = np.random.default_rng(1000 + max_len)
+    flat, offs = synth.make_corpus(256 << 10, "mixed", seed_offset=max_len)
+    toks, scores = synth.random_vocab(rng, bytes(flat[: 64 << 10]), n_multi=3000, max_len=max_len)
+    nat, ora = _pair(toks, scores)
+    assert nat.max_token_len <= max_len
+    assert_same_encoding(nat, ora, flat, offs)
+
+
+def test_sparse_vocab_unreachable_positions():
+    # no single-byte cover: many positions are unreachable, some samples fail
+    rng = np.random.default_rng(5)
+    flat, offs = synth.make_corpus(64 << 10, "ascii", max_len=256)
+    toks, scores = synth.random_vocab(rng, bytes(flat), n_multi=4000, max_len=6, all_bytes=False)
+    nat, ora = _pair(toks, scores)
+    ok = []
+    for i in range(len(offs) - 1):
+        t = bytes(flat[int(offs[i]):int(offs[i + 1])])
+        try:
+            ora.encode(t)
+            ok.append(t)
+        except orc.NoPath:
+            pass
+    # build a few guaranteed-reachable samples by concatenating tokens
+    for _ in range(50):
+        ok.append(b"".join(toks[int(j)] for j in rng.integers(0, len(toks), size=int(rng.integers(1, 60)))))
+    assert _enc(nat, ok) == ora.encode_batch(ok)
+
+
+def test_realistic_vocab_parity_with_ties():
+    flat, offs, toks, scores = corpus_and_vocab(4 << 20, "mixed", 8000, 16)
+    nat, ora = _pair(toks, scores)
+    ids, oo = assert_same_encoding(nat, ora, flat, offs)
+    assert ids.size > 0 and int(oo[-1]) == ids.size
+
+
+def test_long_samples():
+    flat, offs, toks, scores = corpus_and_vocab(3 << 20, "ascii", 4000, 16)
+    nat, ora = _pair(toks, scores)
+    offs2 = np.array([0, 1 << 20, (1 << 20) + 300000, flat.size], dtype=np.uint64)  # 1 MiB, 300 KB, rest
+    assert_same_encoding(nat, ora, flat, offs2)
+
+
+def test_dropout_parity_and_extremes():
+    flat, offs, toks, scores = corpus_and_vocab(512 << 10, "mixed", 3000, 12)
+    nat, ora = _pair(toks, scores)
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.1, seed=42)
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.5, seed=7)
+    ids, oo = assert_same_encoding(nat, ora, flat, offs, dropout=1.0, seed=1)
+    assert ids.size == flat.size  # every multi-byte token dropped (model.rs:217-236)
+
+
+def test_corpus_resident_passes_and_count_tokens():
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 6000, 16)
+    nat, ora = _pair(toks, scores)
+    corpus = tgx.NativeCorpus(flat, offs)
+    r1 = nat.encode_corpus(corpus)
+    r2 = nat.encode_corpus(corpus)
+    want_ids, want_offs = ora.encode_batch_flat(flat, offs, threads=8)
+    np.testing.assert_array_equal(r1.ids(), want_ids)
+    np.testing.assert_array_equal(r2.ids(), want_ids)
+    np.testing.assert_array_equal(r2.offsets(), want_offs)
+    freq = nat.count_tokens(corpus)
+    np.testing.assert_array_equal(freq, np.bincount(want_ids, minlength=len(toks)).astype(np.uint64))
+    np.testing.assert_array_equal(freq, ora.count_tokens_flat(flat, offs, threads=8))
+    times = nat.last_kernel_times()
+    assert "encode_count_kernel" in times and times["encode_count_kernel"] > 0
+    # a second model on the same resident corpus (prune rebuilds the model every sub-iteration)
+    toks2, scores2 = toks[:3000], scores[:3000] * 1.01
+    keep = [bytes([b]) for b in range(256)]
+    toks2 = toks2 + [k for k in keep if k not in set(toks2)]
+    scores2 = np.concatenate([scores2, np.full(len(toks2) - 3000, -12.0)])
+    nat2, ora2 = _pair(toks2, scores2)
+    np.testing.assert_array_equal(nat2.encode_corpus(corpus).ids(), ora2.encode_batch_flat(flat, offs, threads=8)[0])
+
+
+def test_tokenizer_surface_on_gpu():
+    vocab = [(bytes([i]), -8.0, True) for i in range(256)] + [(b"Hello", -3.0, False), (b"lo", -4.0, False),
+                                                                (b" world", -3.5, False), ("你好".encode(), -2.0, False)]
+    tk = tgx.Tokenizer(vocab, [tgx.CrlfProcessor()], ["<EOS>", "random", "<EOS_2>"])
+    base = tk.base_vocab_size()
+    ids = tk.encode("<EOS>Hello world\r\n你好<EOS_2>", 0.0)
+    assert ids == [base + 0, 256, 258, 10, 259, base + 2]
+    assert tk.decode(ids, True) == "<EOS>Hello world\n你好<EOS_2>"
+    assert tk.decode(ids, False) == "Hello world\n你好"
+    batch = tk.encode_batch(["Hello", "", "randomHello"], 0.0)
+    assert batch == [[256], [], [base + 1, 256]]
+    assert tk.encode_ordinary("<EOS>", 0.0) == list(b"<EOS>")
+    assert tk.common_prefix_search("Hello") == [ord("H"), 256]
+    tk2 = tgx.Tokenizer.from_str(tk.to_string())
+    assert tk2.encode_batch(["Hello world<EOS>"], 0.0) == tk.encode_batch(["Hello world<EOS>"], 0.0)
+    with pytest.raises(tgx.TokenGeeXError):
+        tgx.Tokenizer([(b"a", -1.0, False)]).encode("b", 0.0)

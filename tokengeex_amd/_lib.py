@@ -1,0 +1,321 @@
+"""ctypes binding of the C ABI declared in include/tgx.h (tokengeex_amd/libtgx.so).
+
+The extension is mandatory: importing this module raises if libtgx.so is missing
+or does not export a declared symbol, and every compute call raises
+TokenGeeXError when no gfx950 device is usable.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtgx.so")
+
+# tgx_status (include/tgx.h)
+OK, ERR_IO, ERR_JSON, ERR_TOKEN_ID_OOB, ERR_NO_PATH, ERR_DEVICE, ERR_Z_NOT_NORMAL, ERR_INVALID, \
+    ERR_UNSUPPORTED = range(9)
+MAX_TOKEN_LEN = 64
+ESTEP_SNIPPET_LEN = 81920
+
+# every exported symbol of include/tgx.h: name -> (restype, argtypes)
+_vp, _u64, _u32, _i, _d = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+_pvp, _pu64 = C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)
+SYMBOLS = {
+    "tgx_last_error": (C.c_char_p, []),
+    "tgx_last_error_detail": (None, [_pu64, _pu64, _pu64]),
+    "tgx_abi_version": (_i, []),
+    "tgx_device_count": (_i, []),
+    "tgx_model_create": (_i, [_vp, _vp, _vp, _u32, _i, _pvp]),
+    "tgx_model_destroy": (None, [_vp]),
+    "tgx_model_vocab_size": (_u32, [_vp]),
+    "tgx_model_max_token_len": (_u32, [_vp]),
+    "tgx_model_trie_bytes": (_u64, [_vp]),
+    "tgx_model_device": (_i, [_vp]),
+    "tgx_common_prefix_search": (_i, [_vp, _vp, _u64, _vp, _vp, _u64, _pu64]),
+    "tgx_flat_trie_build": (_i, [_vp, _vp, _vp, _u32, _pvp]),
+    "tgx_flat_trie_free": (None, [_vp]),
+    "tgx_flat_trie_search": (_u64, [_vp, _vp, _u64, _vp, _vp, _u64]),
+    "tgx_flat_trie_stats": (None, [_vp, _pu64, _pu64, C.POINTER(C.c_uint32)]),
+    "tgx_dropout_u01_host": (_d, [_u64, _u64, _u64, _u32]),
+    "tgx_encode_batch": (_i, [_vp, _vp, _vp, _u64, _d, _u64, _pvp]),
+    "tgx_result_num_samples": (_u64, [_vp]),
+    "tgx_result_num_tokens": (_u64, [_vp]),
+    "tgx_result_ids": (_vp, [_vp]),
+    "tgx_result_offsets": (_vp, [_vp]),
+    "tgx_result_ids_device": (_vp, [_vp]),
+    "tgx_result_offsets_device": (_vp, [_vp]),
+    "tgx_result_free": (None, [_vp]),
+    "tgx_corpus_upload": (_i, [_i, _vp, _vp, _u64, _pvp]),
+    "tgx_corpus_free": (None, [_vp]),
+    "tgx_corpus_num_samples": (_u64, [_vp]),
+    "tgx_corpus_num_bytes": (_u64, [_vp]),
+    "tgx_encode_corpus": (_i, [_vp, _vp, _d, _u64, _pvp]),
+    "tgx_count_tokens": (_i, [_vp, _vp, _vp]),
+    "tgx_count_pairs": (_i, [_vp, _vp, _pvp, _pvp, _pu64]),
+    "tgx_estep": (_i, [_vp, _vp, _u64, _d, _u64, _vp, C.POINTER(C.c_double)]),
+    "tgx_free": (None, [_vp]),
+    "tgx_last_kernel_times": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i]),
+    "tgx_last_algorithmic_bytes": (_u64, [_vp]),
+}
+
+
+class TokenGeeXError(Exception):
+    """tokengeex.TokenGeeXError — bindings/python/src/lib.rs:9,33-37; carries the
+    reference's Display string (src/lib.rs:238-249)."""
+
+    def __init__(self, message: str, status: int = -1, sample: int | None = None,
+                 pos: int | None = None, length: int | None = None):
+        super().__init__(message)
+        self.status, self.sample, self.pos, self.length = status, sample, pos, length
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is mandatory (no CPU fallback). "
+            "Build it with `python tokengeex_amd/build.py`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.tgx_abi_version() != 1:
+        raise ImportError("libtgx.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int) -> None:
+    if status == OK:
+        return
+    msg = (lib.tgx_last_error() or b"").decode("utf-8", "replace")
+    if status in (ERR_NO_PATH, ERR_Z_NOT_NORMAL):
+        s, p, l = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib.tgx_last_error_detail(C.byref(s), C.byref(p), C.byref(l))
+        raise TokenGeeXError(msg, status, s.value, p.value, l.value)
+    raise TokenGeeXError(msg, status)
+
+
+def device_count() -> int:
+    return lib.tgx_device_count()
+
+
+def ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pack(items) -> tuple[np.ndarray, np.ndarray]:
+    """list[bytes] -> (uint8 flat, uint64 offsets[len+1]) — the ABI's batch format."""
+    offs = np.zeros(len(items) + 1, dtype=np.uint64)
+    if len(items):
+        np.cumsum(np.fromiter((len(t) for t in items), dtype=np.uint64, count=len(items)), out=offs[1:])
+    flat = np.frombuffer(b"".join(items), dtype=np.uint8)
+    return flat, offs
+
+
+class NativeResult:
+    """Owns a tgx_result (ids + offsets of one encode pass)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        self.free()
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib.tgx_result_free(self._h)
+            self._h = None
+
+    @property
+    def num_tokens(self) -> int:
+        return lib.tgx_result_num_tokens(self._h)
+
+    @property
+    def num_samples(self) -> int:
+        return lib.tgx_result_num_samples(self._h)
+
+    def offsets(self) -> np.ndarray:
+        p = lib.tgx_result_offsets(self._h)
+        if not p:
+            check(ERR_DEVICE)
+        n = self.num_samples + 1
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n,)).copy()
+
+    def ids(self) -> np.ndarray:
+        t = self.num_tokens
+        if t == 0:
+            return np.zeros(0, np.uint32)
+        p = lib.tgx_result_ids(self._h)
+        if not p:
+            check(ERR_DEVICE)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(t,)).copy()
+
+    def ids_device_ptr(self) -> int:
+        return lib.tgx_result_ids_device(self._h) or 0
+
+
+class NativeCorpus:
+    """Owns a tgx_corpus: a packed batch resident in HBM across passes."""
+
+    def __init__(self, flat: np.ndarray, offs: np.ndarray, device: int = 0):
+        flat = np.ascontiguousarray(flat, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib.tgx_corpus_upload(device, ptr(flat) if flat.size else None, ptr(offs),
+                                    offs.shape[0] - 1, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def __del__(self):
+        self.free()
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib.tgx_corpus_free(self._h)
+            self._h = None
+
+    @property
+    def num_samples(self) -> int:
+        return lib.tgx_corpus_num_samples(self._h)
+
+    @property
+    def num_bytes(self) -> int:
+        return lib.tgx_corpus_num_bytes(self._h)
+
+
+class NativeModel:
+    """Owns a tgx_model: Model::from(vocab) flattened into HBM (src/model.rs:16-30)."""
+
+    def __init__(self, tokens: list[bytes], scores, device: int = 0):
+        flat, offs = pack(tokens)
+        self._scores = np.ascontiguousarray(scores, dtype=np.float64)
+        if self._scores.shape[0] != len(tokens):
+            raise ValueError("scores and tokens differ in length")
+        h = C.c_void_p()
+        check(lib.tgx_model_create(ptr(flat) if flat.size else None, ptr(offs), ptr(self._scores),
+                                   len(tokens), device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def __del__(self):
+        self.free()
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib.tgx_model_destroy(self._h)
+            self._h = None
+
+    @property
+    def vocab_size(self) -> int:
+        return lib.tgx_model_vocab_size(self._h)
+
+    @property
+    def max_token_len(self) -> int:
+        return lib.tgx_model_max_token_len(self._h)
+
+    @property
+    def trie_bytes(self) -> int:
+        return lib.tgx_model_trie_bytes(self._h)
+
+    def encode_batch_flat(self, flat: np.ndarray, offs: np.ndarray, dropout: float = 0.0,
+                          seed: int = 0) -> NativeResult:
+        flat = np.ascontiguousarray(flat, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib.tgx_encode_batch(self._h, ptr(flat) if flat.size else None, ptr(offs),
+                                   offs.shape[0] - 1, float(dropout), seed & (2**64 - 1), C.byref(h)))
+        return NativeResult(h)
+
+    def encode_corpus(self, corpus: NativeCorpus, dropout: float = 0.0, seed: int = 0) -> NativeResult:
+        h = C.c_void_p()
+        check(lib.tgx_encode_corpus(self._h, corpus._h, float(dropout), seed & (2**64 - 1), C.byref(h)))
+        return NativeResult(h)
+
+    def count_tokens(self, corpus: NativeCorpus, freq: np.ndarray | None = None) -> np.ndarray:
+        if freq is None:
+            freq = np.zeros(self.vocab_size, np.uint64)
+        assert freq.dtype == np.uint64 and freq.shape[0] == self.vocab_size and freq.flags.c_contiguous
+        check(lib.tgx_count_tokens(self._h, corpus._h, ptr(freq)))
+        return freq
+
+    def count_pairs(self, corpus: NativeCorpus) -> tuple[np.ndarray, np.ndarray]:
+        keys, counts, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        check(lib.tgx_count_pairs(self._h, corpus._h, C.byref(keys), C.byref(counts), C.byref(n)))
+        k = n.value
+        ka = np.ctypeslib.as_array(C.cast(keys, C.POINTER(C.c_uint64)), shape=(max(k, 1),))[:k].copy()
+        ca = np.ctypeslib.as_array(C.cast(counts, C.POINTER(C.c_uint64)), shape=(max(k, 1),))[:k].copy()
+        lib.tgx_free(keys)
+        lib.tgx_free(counts)
+        return ka, ca
+
+    def estep(self, corpus: NativeCorpus, snippet_len: int = ESTEP_SNIPPET_LEN, dropout: float = 0.0,
+              seed: int = 0, expected: np.ndarray | None = None) -> tuple[np.ndarray, float]:
+        if expected is None:
+            expected = np.zeros(self.vocab_size, np.float64)
+        assert expected.dtype == np.float64 and expected.shape[0] == self.vocab_size
+        z = C.c_double()
+        check(lib.tgx_estep(self._h, corpus._h, snippet_len, float(dropout), seed & (2**64 - 1),
+                            ptr(expected), C.byref(z)))
+        return expected, z.value
+
+    def common_prefix_search(self, s: bytes) -> list[tuple[int, int]]:
+        buf = np.frombuffer(s, dtype=np.uint8)
+        cap = len(s) + 1
+        ids, lens = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        cnt = C.c_uint64()
+        check(lib.tgx_common_prefix_search(self._h, ptr(buf) if len(s) else None, len(s), ptr(ids),
+                                           ptr(lens), cap, C.byref(cnt)))
+        return [(int(ids[i]), int(lens[i])) for i in range(cnt.value)]
+
+    def last_kernel_times(self) -> dict[str, float]:
+        names = (C.c_char_p * 8)()
+        ms = (C.c_float * 8)()
+        n = lib.tgx_last_kernel_times(self._h, names, ms, 8)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    def last_algorithmic_bytes(self) -> int:
+        return lib.tgx_last_algorithmic_bytes(self._h)
+
+
+class FlatTrie:
+    """Host-only build of the device trie layout (tgx_flat_trie_*), no GPU needed."""
+
+    def __init__(self, tokens: list[bytes], scores):
+        flat, offs = pack(tokens)
+        sc = np.ascontiguousarray(scores, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib.tgx_flat_trie_build(ptr(flat) if flat.size else None, ptr(offs), ptr(sc), len(tokens),
+                                      C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.tgx_flat_trie_free(self._h)
+            self._h = None
+
+    def common_prefix_search(self, s: bytes) -> list[tuple[int, int]]:
+        buf = np.frombuffer(s, dtype=np.uint8)
+        cap = len(s) + 1
+        ids, lens = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        k = lib.tgx_flat_trie_search(self._h, ptr(buf) if len(s) else None, len(s), ptr(ids), ptr(lens), cap)
+        return [(int(ids[i]), int(lens[i])) for i in range(k)]
+
+    def stats(self) -> dict:
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        lib.tgx_flat_trie_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return {"n_slots": a.value, "n_nodes": b.value, "max_token_len": c.value,
+                "fill": b.value / max(1, a.value)}
+
+    @property
+    def max_token_len(self) -> int:
+        return self.stats()["max_token_len"]
+
+
+def dropout_u01(seed: int, sample: int, pos: int, length: int) -> float:
+    return lib.tgx_dropout_u01_host(seed, sample, pos, length)

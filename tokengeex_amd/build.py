@@ -1,0 +1,68 @@
+"""Builds tokengeex_amd/libtgx.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+    python tokengeex_amd/build.py [--force]      (run as a script: importing the package needs the .so)
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the
+GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libtgx.so")
+SOURCES = ["kernels.hip", "tgx_api.cpp", "trie_build.cpp"]
+HEADERS = ["kernels.h", "trie_build.h", os.path.join("..", "..", "include", "tgx.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+SYNTH_OUT = os.path.join(HERE, "libtgx_synth.so")
+
+
+def build_synth(force: bool = False) -> str:
+    """Host-only corpus generator used by bench.py / tests (gcc, no GPU code)."""
+    src = os.path.join(CSRC, "synth_gen.c")
+    if not force and os.path.exists(SYNTH_OUT) and os.path.getmtime(SYNTH_OUT) >= os.path.getmtime(src):
+        return SYNTH_OUT
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-o", SYNTH_OUT + ".tmp", src, "-lm"])
+    os.replace(SYNTH_OUT + ".tmp", SYNTH_OUT)
+    return SYNTH_OUT
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    build_synth(force)
+    if not force and not needs_build():
+        return OUT
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off",  # the DP's f64 adds must not be fused or reassociated
+           "-Wall", "-Wno-unused-result",
+           "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + [
+           "-o", OUT + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,45 @@
+// Kernel parameter blocks and launchers shared by kernels.hip and tgx_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tgx {
+
+enum { MODE_ENCODE = 0, MODE_COUNT = 1 };
+
+struct EncodeParams {
+    const uint8_t* text;            // u8[N (+ pad)]
+    const uint64_t* offs;           // u64[S+1]
+    const uint32_t* order;          // u32[S] sample processing order (longest first)
+    uint64_t n_samples;
+    const void* trie;               // TrieRec[n_slots] (16 B each)
+    const uint32_t* tokid;          // u32[n_slots]
+    uint32_t root_base;
+    uint32_t lm;                    // max token length rounded up (<= 64)
+    uint32_t* bp;                   // u32[N] back-pointer scratch
+    uint32_t* tmp;                  // u32[N] right-aligned ids per sample (MODE_ENCODE)
+    uint32_t* counts;               // u32[S] tokens per sample
+    unsigned long long* freq;       // u64[V] histogram (MODE_COUNT)
+    unsigned long long* next;       // work counter (zeroed before launch)
+    unsigned long long* err_sample; // min failing sample (init ~0)
+    double dropout;
+    uint64_t seed;
+};
+
+struct CompactParams {
+    const uint64_t* offs;
+    const uint32_t* order;
+    uint64_t n_samples;
+    const uint32_t* tmp;
+    const uint64_t* out_offs;
+    uint32_t* ids;
+    unsigned long long* next;
+};
+
+uint32_t encode_lds_bytes_per_block(uint32_t lm);
+hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out);
+hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
+hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);
+hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);
+
+}  // namespace tgx

@@ -1,0 +1,300 @@
+// HIP kernels (gfx950 / CDNA4, wave64) for the Unigram encode path.
+//
+// Replaces the reference's Model::encode (src/model.rs:59-129) + the rayon batch
+// loop (src/tokenizer.rs:102-123).  One WAVEFRONT per sample:
+//
+//   match  : lane i walks the flattened trie from byte position p0+i (64
+//            positions in parallel; one 16-byte gather per trie step), leaving a
+//            bitmask of matching lengths in a register and (score, handle) per
+//            match in LDS.
+//   relax  : positions are then finalised in order.  Lane j is the accumulator of
+//            the end position e with e % 64 == j; finalising position p pushes
+//            best[p] + score(p, L) into lane (p + L) % 64 for every match of
+//            length L at once (one f64 add + compare per lane).  Candidates reach
+//            each accumulator in ascending start order and replace it only on a
+//            strict '>', i.e. exactly the reference's relaxation order
+//            (model.rs:83-110): bit-exact scores, longest-token-wins ties.
+//   trace  : back-pointers (slot << 6 | len - 1) go to an HBM scratch row per
+//            sample; the same wave walks them back 64 positions at a time with
+//            scalar readlane hops and writes the token ids right-aligned into the
+//            sample's slice of a temporary row.
+//
+// No MFMA: this is byte indexing plus f64 add/compare.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace tgx {
+
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, uint32_t lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t lane) {
+    uint32_t lo = readlane_u32((uint32_t)v, lane);
+    uint32_t hi = readlane_u32((uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, uint32_t lane) {
+    return __longlong_as_double((long long)readlane_u64((uint64_t)__double_as_longlong(v), lane));
+}
+__device__ __forceinline__ uint64_t first_u64(uint64_t v) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, uint32_t r) {
+    r &= 63u;
+    return (x << r) | (x >> ((64u - r) & 63u));
+}
+
+// same function as tgx_dropout_u01 in include/tgx.h
+__device__ __forceinline__ double dropout_u01(uint64_t seed, uint64_t sample, uint64_t pos, uint32_t len) {
+    uint64_t x = seed ^ (sample * 0x9E3779B97F4A7C15ULL) ^ (pos * 0xC2B2AE3D27D4EB4FULL) ^
+                 ((uint64_t)len * 0x165667B19E3779F9ULL);
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// LDS bytes one wave needs for a given (rounded) max token length.
+__host__ __device__ inline uint32_t wave_lds_bytes(uint32_t lm) {
+    uint32_t entries = 64u * lm + 64u;  // +64: inactive lanes may read past a row
+    return entries * 8u + entries * 4u + 128u;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t LM = P.lm;
+    const uint32_t entries = 64u * LM + 64u;
+    unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(LM);
+    double* sc = reinterpret_cast<double*>(wbase);
+    uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + (size_t)entries * 8u);
+    uint8_t* txt = reinterpret_cast<uint8_t*>(wbase + (size_t)entries * 12u);
+    const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
+    const bool use_dropout = P.dropout > 0.0;
+
+    for (;;) {
+        unsigned long long k = 0;
+        if (lane == 0) k = atomicAdd(P.next, 1ULL);
+        k = first_u64(k);
+        if (k >= P.n_samples) break;  // every wave reaches this: the counter only grows
+        const uint32_t s = P.order[k];
+        const uint64_t beg = P.offs[s];
+        const uint32_t n = (uint32_t)(P.offs[s + 1] - beg);
+        const uint8_t* __restrict__ text = P.text + beg;
+        uint32_t* __restrict__ bp = P.bp + beg;  // bp[e - 1] for end position e in 1..n
+
+        double acc = 0.0;    // best[e] of the end position this lane accumulates
+        uint32_t bpv = 0;    // its back-pointer: slot << 6 | (len - 1)
+        uint64_t reach = 1;  // wave-uniform: bit j = lane j holds a value (position 0: score 0)
+        uint32_t reach_n = (n == 0) ? 1u : 0u;
+
+        for (uint32_t p0 = 0; p0 <= n; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            // ---- stage the block's text (+ LM look-ahead) in LDS
+            txt[lane] = (p < n) ? text[p] : (uint8_t)0;
+            txt[lane + 64] = (p + 64 < n) ? text[p + 64] : (uint8_t)0;
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- match: TrieIterator::next (trie.rs:51-63) for 64 start positions at once
+            const uint32_t rem = (p < n) ? (n - p) : 0u;
+            const uint32_t maxd = rem < LM ? rem : LM;
+            uint32_t cur = 0, base = P.root_base;
+            uint64_t m = 0;
+            bool alive = maxd > 0;
+            for (uint32_t d = 0; d < LM; ++d) {
+                alive = alive && (d < maxd);
+                if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+                if (alive) {
+                    const uint32_t c = txt[lane + d];
+                    const uint32_t t = base ^ c;
+                    const uint4 r = trie[t];
+                    if (r.x == cur) {
+                        cur = t;
+                        base = r.y & 0x7FFFFFFFu;
+                        if (r.y >> 31) {
+                            bool keep = true;
+                            // model.rs:100: kept iff dropout <= 0 || len <= 1 || dropout < rand
+                            if (use_dropout && d >= 1)
+                                keep = P.dropout < dropout_u01(P.seed, s, p, d + 1);
+                            if (keep) {
+                                m |= 1ULL << d;
+                                sc[lane * LM + d] = __hiloint2double((int)r.w, (int)r.z);
+                                hl[lane * LM + d] = (t << 6) | d;
+                            }
+                        }
+                    } else {
+                        alive = false;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- relax: finalise positions p0 .. p0+63 in order (model.rs:83-110)
+            const uint32_t left = n - p0;  // positions < n in this block: min(64, left)
+            const uint32_t steps = left < 64u ? left : 64u;
+            uint32_t fin = 0;
+            for (uint32_t i = 0; i < steps; ++i) {
+                fin = (lane == i) ? bpv : fin;  // back-pointer of position p0+i is final now
+                if (!((reach >> i) & 1ULL)) continue;  // model.rs:85-87 unreachable: skip
+                const double best = readlane_f64(acc, i);
+                const uint64_t mi = readlane_u64(m, i);
+                reach &= ~(1ULL << i);  // lane i now accumulates position p0 + i + 64
+                if (mi == 0) continue;
+                const uint64_t active = rotl64(mi, i + 1);  // length L -> lane (i + L) % 64
+                const uint32_t tj = (lane - i - 1u) & 63u;   // L - 1 for this lane
+                const double sv = sc[i * LM + tj];
+                const uint32_t hv = hl[i * LM + tj];
+                const double cand = best + sv;  // model.rs:98
+                const bool act = (active >> lane) & 1ULL;
+                const bool had = (reach >> lane) & 1ULL;
+                const bool take = act && (!had || cand > acc);  // model.rs:101 strict '>'
+                acc = take ? cand : acc;
+                bpv = take ? hv : bpv;
+                reach |= active;
+            }
+            if (left < 64u) {  // position n itself sits in this block
+                fin = (lane == left) ? bpv : fin;
+                reach_n = (uint32_t)((reach >> left) & 1ULL);
+            }
+            const uint32_t e = p0 + lane;
+            if (e >= 1 && e <= n) bp[e - 1] = fin;
+        }
+
+        if (!reach_n) {  // Error::NoPath(n, n), model.rs:119
+            if (lane == 0) {
+                atomicMin(P.err_sample, (unsigned long long)s);
+                P.counts[s] = 0;
+            }
+            continue;
+        }
+
+        // ---- trace: follow the back-pointers from n (model.rs:113-126), 64 positions per hop group
+        __threadfence_block();  // this wave's bp stores above are read back below
+        uint32_t total = 0;
+        uint64_t cursor = beg + n;  // one past this sample's slice of tmp
+        int64_t q = (int64_t)n - 1; // index into bp of the current end position
+        while (q >= 0) {
+            const uint32_t wq = (uint32_t)q & ~63u;
+            const uint32_t idx = wq + lane;
+            const uint32_t h = (idx < n) ? bp[idx] : 0u;
+            uint64_t ends = 0;
+            int32_t qq = (int32_t)((uint32_t)q - wq);
+            while (qq >= 0) {
+                const uint32_t hh = readlane_u32(h, (uint32_t)qq);
+                ends |= 1ULL << qq;
+                qq -= (int32_t)(hh & 63u) + 1;
+            }
+            q = (int64_t)wq + qq;
+            const uint32_t cnt = (uint32_t)__popcll(ends);
+            if ((ends >> lane) & 1ULL) {
+                const uint32_t id = P.tokid[h >> 6];
+                if (MODE == MODE_ENCODE) {
+                    const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
+                    P.tmp[cursor - 1 - above] = id;
+                } else {
+                    atomicAdd(&P.freq[id], 1ULL);
+                }
+            }
+            cursor -= cnt;
+            total += cnt;
+        }
+        if (lane == 0) P.counts[s] = total;
+    }
+}
+
+// counts[S] -> offsets[S+1] (exclusive prefix sum), one workgroup.
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __restrict__ counts,
+                                                           uint64_t* __restrict__ offsets,
+                                                           uint64_t n) {
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + tid;
+        uint64_t v = (i < n) ? counts[i] : 0;
+        uint64_t x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint64_t y = __shfl_up(x, off);
+            if ((int)lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint64_t wprefix = 0;
+        for (uint32_t w = 0; w < wave; ++w) wprefix += wsum[w];
+        const uint64_t carry = carry_s;
+        if (i < n) offsets[i] = carry + wprefix + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + wprefix + x;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[n] = carry_s;
+}
+
+// tmp (right-aligned per sample) -> ids (packed), one wave per sample.
+__global__ __launch_bounds__(256) void compact_kernel(CompactParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        unsigned long long k = 0;
+        if (lane == 0) k = atomicAdd(P.next, 1ULL);
+        k = first_u64(k);
+        if (k >= P.n_samples) break;
+        const uint32_t s = P.order[k];
+        const uint64_t end = P.offs[s + 1];
+        const uint64_t o0 = P.out_offs[s];
+        const uint32_t cnt = (uint32_t)(P.out_offs[s + 1] - o0);
+        const uint32_t* __restrict__ src = P.tmp + (end - cnt);
+        uint32_t* __restrict__ dst = P.ids + o0;
+        for (uint32_t i = lane; i < cnt; i += 64) dst[i] = src[i];
+    }
+}
+
+// ---- launchers -------------------------------------------------------------
+
+uint32_t encode_lds_bytes_per_block(uint32_t lm) { return 4u * wave_lds_bytes(lm); }
+
+hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream) {
+    const uint32_t lds = encode_lds_bytes_per_block(p.lm);
+    if (mode == MODE_ENCODE)
+        hipLaunchKernelGGL(encode_kernel<MODE_ENCODE>, dim3(blocks), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL(encode_kernel<MODE_COUNT>, dim3(blocks), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out) {
+    const uint32_t lds = encode_lds_bytes_per_block(lm);
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e;
+    if (mode == MODE_ENCODE) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel<MODE_ENCODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode_kernel<MODE_ENCODE>, 256, lds);
+    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel<MODE_COUNT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode_kernel<MODE_COUNT>, 256, lds);
+}
+
+hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts, offsets, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace tgx

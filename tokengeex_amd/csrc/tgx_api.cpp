@@ -1,0 +1,626 @@
+// C ABI (include/tgx.h) over the HIP kernels: handles, HBM buffers, launch
+// sequencing, error reporting.  Host side of the reference's batch loops
+// (src/tokenizer.rs:102-123, src/prune.rs:205-244); there is no CPU fallback —
+// without a usable gfx950 device every compute entry point returns TGX_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/tgx.h"
+#include "kernels.h"
+#include "trie_build.h"
+
+namespace {
+
+// ---- thread-local error state ------------------------------------------------
+thread_local std::string g_err_msg;
+thread_local uint64_t g_err_sample = 0, g_err_pos = 0, g_err_len = 0;
+
+tgx_status fail(tgx_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err_msg = buf;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(TGX_ERR_DEVICE, "HIP error %d (%s) at %s:%d: %s", (int)_e,        \
+                        hipGetErrorString(_e), __FILE__, __LINE__, #expr);                \
+    } while (0)
+
+// ---- device buffer pool --------------------------------------------------------
+// hipMalloc/hipFree cost far more than a kernel launch; scratch and result
+// buffers are recycled through a small per-process free list.
+struct PoolEntry {
+    void* ptr;
+    size_t bytes;
+    int device;
+};
+std::mutex g_pool_mu;
+std::vector<PoolEntry> g_pool;
+size_t g_pool_bytes = 0;
+constexpr size_t kPoolMaxBytes = 96ull << 30;
+
+hipError_t pool_alloc(int device, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~size_t(255);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t best = g_pool.size();
+        for (size_t i = 0; i < g_pool.size(); i++) {
+            const PoolEntry& e = g_pool[i];
+            if (e.device != device || e.bytes < bytes || e.bytes > bytes * 2 + (1u << 20)) continue;
+            if (best == g_pool.size() || e.bytes < g_pool[best].bytes) best = i;
+        }
+        if (best != g_pool.size()) {
+            *out = g_pool[best].ptr;
+            g_pool_bytes -= g_pool[best].bytes;
+            g_pool.erase(g_pool.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    return hipMalloc(out, bytes);
+}
+
+size_t rounded(size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    return (bytes + 255) & ~size_t(255);
+}
+
+void pool_free(int device, void* ptr, size_t bytes) {
+    if (!ptr) return;
+    bytes = rounded(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool_bytes + bytes <= kPoolMaxBytes && g_pool.size() < 256) {
+            g_pool.push_back(PoolEntry{ptr, bytes, device});
+            g_pool_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipSetDevice(device);
+    (void)hipFree(ptr);
+}
+
+struct KernelTime {
+    const char* name;
+    hipEvent_t start, stop;
+    bool used;
+};
+constexpr int kMaxTimed = 8;
+
+}  // namespace
+
+struct tgx_model {
+    int device = 0;
+    uint32_t vocab_size = 0;
+    uint32_t lm = 0;  // max token length rounded up to a multiple of 4 (>= 4)
+    tgx::FlatTrie flat;
+    void* d_trie = nullptr;
+    uint32_t* d_tokid = nullptr;
+    unsigned long long* d_ctrl = nullptr;  // [0] work counter, [1] min failing sample
+    unsigned long long* h_ctrl = nullptr;  // pinned: [0] err sample, [1] total tokens
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    int blocks_per_cu[2] = {0, 0};
+    KernelTime timed[kMaxTimed] = {};
+    int n_timed = 0;
+    uint64_t last_alg_bytes = 0;
+    std::mutex mu;  // one pass at a time per handle (its stream, counters and events)
+};
+
+struct tgx_corpus {
+    int device = 0;
+    uint64_t n_samples = 0, n_bytes = 0;
+    std::vector<uint64_t> h_offs;
+    uint8_t* d_text = nullptr;
+    uint64_t* d_offs = nullptr;
+    uint32_t* d_order = nullptr;
+    uint32_t* d_bp = nullptr;      // scratch, allocated on first pass
+    uint32_t* d_tmp = nullptr;
+    uint32_t* d_counts = nullptr;
+};
+
+struct tgx_result {
+    int device = 0;
+    uint64_t n_samples = 0, n_tokens = 0;
+    uint32_t* d_ids = nullptr;
+    uint64_t* d_offs = nullptr;
+    std::vector<uint32_t> h_ids;
+    std::vector<uint64_t> h_offs;
+    bool have_ids = false, have_offs = false;
+};
+
+namespace {
+
+int usable_device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+void time_begin(tgx_model* m, const char* name) {
+    if (m->n_timed >= kMaxTimed) return;
+    KernelTime& t = m->timed[m->n_timed];
+    t.name = name;
+    t.used = true;
+    (void)hipEventRecord(t.start, m->stream);
+}
+void time_end(tgx_model* m) {
+    if (m->n_timed >= kMaxTimed) return;
+    (void)hipEventRecord(m->timed[m->n_timed].stop, m->stream);
+    m->n_timed++;
+}
+
+tgx_status ensure_scratch(tgx_corpus* c) {
+    if (c->d_bp) return TGX_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(pool_alloc(c->device, (size_t)c->n_bytes * 4 + 256, (void**)&c->d_bp));
+    HIP_TRY(pool_alloc(c->device, (size_t)c->n_bytes * 4 + 256, (void**)&c->d_tmp));
+    HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_counts));
+    return TGX_OK;
+}
+
+uint32_t grid_blocks(const tgx_model* m, int mode, uint64_t n_samples) {
+    uint64_t want = (n_samples + 3) / 4;
+    uint64_t cap = (uint64_t)m->num_cus * (uint64_t)std::max(1, m->blocks_per_cu[mode]);
+    return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
+}
+
+// Runs the wave-per-sample kernel over the corpus; on return (stream synced)
+// h_ctrl[0] = min failing sample (~0 if none).
+tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropout, uint64_t seed,
+                             unsigned long long* d_freq) {
+    tgx_status st = ensure_scratch(c);
+    if (st != TGX_OK) return st;
+    HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));
+    HIP_TRY(hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream));
+    tgx::EncodeParams p{};
+    p.text = c->d_text;
+    p.offs = c->d_offs;
+    p.order = c->d_order;
+    p.n_samples = c->n_samples;
+    p.trie = m->d_trie;
+    p.tokid = m->d_tokid;
+    p.root_base = m->flat.table[0].base & ~tgx::kTerminalBit;
+    p.lm = m->lm;
+    p.bp = c->d_bp;
+    p.tmp = c->d_tmp;
+    p.counts = c->d_counts;
+    p.freq = d_freq;
+    p.next = m->d_ctrl;
+    p.err_sample = m->d_ctrl + 1;
+    p.dropout = dropout;
+    p.seed = seed;
+    time_begin(m, mode == tgx::MODE_ENCODE ? "encode_kernel" : "encode_count_kernel");
+    HIP_TRY(tgx::launch_encode(p, mode, grid_blocks(m, mode, c->n_samples), m->stream));
+    time_end(m);
+    return TGX_OK;
+}
+
+tgx_status check_no_path(tgx_model* m, const tgx_corpus* c) {
+    unsigned long long bad = m->h_ctrl[0];
+    if (bad == ~0ULL) return TGX_OK;
+    uint64_t n = c->h_offs[bad + 1] - c->h_offs[bad];
+    g_err_sample = bad;
+    g_err_pos = n;
+    g_err_len = n;
+    // Display of Error::NoPath, reference src/lib.rs:243-245
+    return fail(TGX_ERR_NO_PATH, "no path to position %llu/%llu", (unsigned long long)n,
+                (unsigned long long)n);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tgx_last_error(void) { return g_err_msg.c_str(); }
+
+void tgx_last_error_detail(uint64_t* sample, uint64_t* pos, uint64_t* len) {
+    if (sample) *sample = g_err_sample;
+    if (pos) *pos = g_err_pos;
+    if (len) *len = g_err_len;
+}
+
+int tgx_abi_version(void) { return TGX_ABI_VERSION; }
+int tgx_device_count(void) { return usable_device_count(); }
+void tgx_free(void* p) { free(p); }
+
+tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const double* scores,
+                            uint32_t vocab_size, int device, tgx_model** out) {
+    if (!out) return fail(TGX_ERR_INVALID, "tgx_model_create: out is NULL");
+    *out = nullptr;
+    if (vocab_size && (!offs || !scores)) return fail(TGX_ERR_INVALID, "tgx_model_create: NULL vocab");
+    int ndev = usable_device_count();
+    if (ndev <= 0) return fail(TGX_ERR_DEVICE, "no usable HIP device (gfx950 required)");
+    if (device < 0 || device >= ndev)
+        return fail(TGX_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+
+    tgx_model* m = new tgx_model();
+    m->device = device;
+    m->vocab_size = vocab_size;
+    static const uint64_t zero_offs[1] = {0};
+    tgx::build_flat_trie(bytes, vocab_size ? offs : zero_offs, scores, vocab_size, &m->flat);
+    if (m->flat.max_token_len > TGX_MAX_TOKEN_LEN) {
+        uint32_t l = m->flat.max_token_len;
+        delete m;
+        return fail(TGX_ERR_UNSUPPORTED, "token of %u bytes exceeds TGX_MAX_TOKEN_LEN (%d)", l,
+                    TGX_MAX_TOKEN_LEN);
+    }
+    if (m->flat.table.size() >= (1u << 26)) {
+        delete m;
+        return fail(TGX_ERR_UNSUPPORTED, "trie needs more than 2^26 slots");
+    }
+    m->lm = std::max<uint32_t>(4, (m->flat.max_token_len + 3) & ~3u);
+
+    auto cleanup = [&](tgx_status st) {
+        tgx_model_destroy(m);
+        return st;
+    };
+#define HIP_TRY_M(expr)                                                                     \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return cleanup(fail(TGX_ERR_DEVICE, "HIP error %d (%s) at %s:%d: %s", (int)_e,  \
+                                hipGetErrorString(_e), __FILE__, __LINE__, #expr));         \
+    } while (0)
+    HIP_TRY_M(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY_M(hipGetDeviceProperties(&prop, device));
+    m->num_cus = prop.multiProcessorCount;
+    HIP_TRY_M(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    size_t tbytes = m->flat.table.size() * sizeof(tgx::TrieRec);
+    HIP_TRY_M(hipMalloc(&m->d_trie, tbytes));
+    HIP_TRY_M(hipMalloc((void**)&m->d_tokid, m->flat.tokid.size() * 4));
+    HIP_TRY_M(hipMalloc((void**)&m->d_ctrl, 64));
+    HIP_TRY_M(hipHostMalloc((void**)&m->h_ctrl, 64, hipHostMallocDefault));
+    HIP_TRY_M(hipMemcpyAsync(m->d_trie, m->flat.table.data(), tbytes, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY_M(hipMemcpyAsync(m->d_tokid, m->flat.tokid.data(), m->flat.tokid.size() * 4,
+                             hipMemcpyHostToDevice, m->stream));
+    for (int i = 0; i < kMaxTimed; i++) {
+        m->timed[i].used = false;
+        m->timed[i].name = "";
+        HIP_TRY_M(hipEventCreate(&m->timed[i].start));
+        HIP_TRY_M(hipEventCreate(&m->timed[i].stop));
+    }
+    for (int mode = 0; mode < 2; mode++) {
+        int occ = 0;
+        HIP_TRY_M(tgx::encode_max_blocks_per_cu(m->lm, mode, &occ));
+        m->blocks_per_cu[mode] = std::max(1, std::min(occ, 8));
+    }
+    HIP_TRY_M(hipStreamSynchronize(m->stream));
+#undef HIP_TRY_M
+    *out = m;
+    return TGX_OK;
+}
+
+void tgx_model_destroy(tgx_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (int i = 0; i < kMaxTimed; i++) {
+        if (m->timed[i].start) (void)hipEventDestroy(m->timed[i].start);
+        if (m->timed[i].stop) (void)hipEventDestroy(m->timed[i].stop);
+    }
+    if (m->d_trie) (void)hipFree(m->d_trie);
+    if (m->d_tokid) (void)hipFree(m->d_tokid);
+    if (m->d_ctrl) (void)hipFree(m->d_ctrl);
+    if (m->h_ctrl) (void)hipHostFree(m->h_ctrl);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+uint32_t tgx_model_vocab_size(const tgx_model* m) { return m ? m->vocab_size : 0; }
+uint32_t tgx_model_max_token_len(const tgx_model* m) { return m ? m->flat.max_token_len : 0; }
+uint64_t tgx_model_trie_bytes(const tgx_model* m) {
+    return m ? (uint64_t)m->flat.table.size() * sizeof(tgx::TrieRec) : 0;
+}
+int tgx_model_device(const tgx_model* m) { return m ? m->device : -1; }
+
+tgx_status tgx_common_prefix_search(const tgx_model* m, const uint8_t* s, uint64_t n, uint32_t* ids,
+                                    uint32_t* lens, uint64_t cap, uint64_t* count) {
+    if (!m || !count) return fail(TGX_ERR_INVALID, "tgx_common_prefix_search: NULL argument");
+    *count = tgx::flat_common_prefix_search(m->flat, s, n, ids, lens, cap);
+    return TGX_OK;
+}
+
+// ---- host-only trie introspection ----------------------------------------------
+
+struct tgx_flat_trie {
+    tgx::FlatTrie flat;
+};
+
+tgx_status tgx_flat_trie_build(const uint8_t* bytes, const uint64_t* offs, const double* scores,
+                               uint32_t vocab_size, tgx_flat_trie** out) {
+    if (!out) return fail(TGX_ERR_INVALID, "tgx_flat_trie_build: out is NULL");
+    static const uint64_t zero_offs[1] = {0};
+    tgx_flat_trie* t = new tgx_flat_trie();
+    tgx::build_flat_trie(bytes, vocab_size ? offs : zero_offs, scores, vocab_size, &t->flat);
+    *out = t;
+    return TGX_OK;
+}
+void tgx_flat_trie_free(tgx_flat_trie* t) { delete t; }
+uint64_t tgx_flat_trie_search(const tgx_flat_trie* t, const uint8_t* s, uint64_t n, uint32_t* ids,
+                              uint32_t* lens, uint64_t cap) {
+    return t ? tgx::flat_common_prefix_search(t->flat, s, n, ids, lens, cap) : 0;
+}
+void tgx_flat_trie_stats(const tgx_flat_trie* t, uint64_t* n_slots, uint64_t* n_nodes,
+                         uint32_t* max_token_len) {
+    if (!t) return;
+    if (n_slots) *n_slots = t->flat.table.size();
+    if (n_nodes) *n_nodes = t->flat.n_nodes;
+    if (max_token_len) *max_token_len = t->flat.max_token_len;
+}
+double tgx_dropout_u01_host(uint64_t seed, uint64_t sample, uint64_t pos, uint32_t len) {
+    return tgx_dropout_u01(seed, sample, pos, len);
+}
+
+// ---- corpus ------------------------------------------------------------------
+
+tgx_status tgx_corpus_upload(int device, const uint8_t* text, const uint64_t* offs,
+                             uint64_t n_samples, tgx_corpus** out) {
+    if (!out) return fail(TGX_ERR_INVALID, "tgx_corpus_upload: out is NULL");
+    *out = nullptr;
+    if (n_samples && !offs) return fail(TGX_ERR_INVALID, "tgx_corpus_upload: offs is NULL");
+    int ndev = usable_device_count();
+    if (ndev <= 0) return fail(TGX_ERR_DEVICE, "no usable HIP device (gfx950 required)");
+    if (device < 0 || device >= ndev)
+        return fail(TGX_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    if (n_samples >= 0xFFFFFFFFull) return fail(TGX_ERR_UNSUPPORTED, "more than 2^32-1 samples");
+    const uint64_t base = n_samples ? offs[0] : 0;
+    for (uint64_t i = 0; i < n_samples; i++) {
+        if (offs[i + 1] < offs[i]) return fail(TGX_ERR_INVALID, "offsets not monotone at %llu",
+                                               (unsigned long long)i);
+        if (offs[i + 1] - offs[i] >= 0xFFFFFF00ull)
+            return fail(TGX_ERR_UNSUPPORTED, "sample %llu is 4 GiB or longer", (unsigned long long)i);
+    }
+    tgx_corpus* c = new tgx_corpus();
+    c->device = device;
+    c->n_samples = n_samples;
+    c->n_bytes = n_samples ? offs[n_samples] - base : 0;
+    c->h_offs.resize(n_samples + 1);
+    for (uint64_t i = 0; i <= n_samples; i++) c->h_offs[i] = n_samples ? offs[i] - base : 0;
+    if (n_samples && c->n_bytes && !text) {
+        delete c;
+        return fail(TGX_ERR_INVALID, "tgx_corpus_upload: text is NULL");
+    }
+    // longest first: the tail of a pass is then made of short samples
+    std::vector<uint32_t> order(n_samples);
+    std::iota(order.begin(), order.end(), 0u);
+    const uint64_t* ho = c->h_offs.data();
+    std::stable_sort(order.begin(), order.end(), [ho](uint32_t a, uint32_t b) {
+        return ho[a + 1] - ho[a] > ho[b + 1] - ho[b];
+    });
+
+    auto cleanup = [&](tgx_status st) {
+        tgx_corpus_free(c);
+        return st;
+    };
+#define HIP_TRY_C(expr)                                                                     \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return cleanup(fail(TGX_ERR_DEVICE, "HIP error %d (%s) at %s:%d: %s", (int)_e,  \
+                                hipGetErrorString(_e), __FILE__, __LINE__, #expr));         \
+    } while (0)
+    HIP_TRY_C(hipSetDevice(device));
+    HIP_TRY_C(pool_alloc(device, (size_t)c->n_bytes + 256, (void**)&c->d_text));
+    HIP_TRY_C(pool_alloc(device, (size_t)(n_samples + 1) * 8, (void**)&c->d_offs));
+    HIP_TRY_C(pool_alloc(device, (size_t)n_samples * 4 + 4, (void**)&c->d_order));
+    if (c->n_bytes) HIP_TRY_C(hipMemcpy(c->d_text, text + base, c->n_bytes, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemset(c->d_text + c->n_bytes, 0, 256));
+    HIP_TRY_C(hipMemcpy(c->d_offs, c->h_offs.data(), (n_samples + 1) * 8, hipMemcpyHostToDevice));
+    if (n_samples) HIP_TRY_C(hipMemcpy(c->d_order, order.data(), n_samples * 4, hipMemcpyHostToDevice));
+#undef HIP_TRY_C
+    *out = c;
+    return TGX_OK;
+}
+
+void tgx_corpus_free(tgx_corpus* c) {
+    if (!c) return;
+    pool_free(c->device, c->d_text, (size_t)c->n_bytes + 256);
+    pool_free(c->device, c->d_offs, (size_t)(c->n_samples + 1) * 8);
+    pool_free(c->device, c->d_order, (size_t)c->n_samples * 4 + 4);
+    pool_free(c->device, c->d_bp, (size_t)c->n_bytes * 4 + 256);
+    pool_free(c->device, c->d_tmp, (size_t)c->n_bytes * 4 + 256);
+    pool_free(c->device, c->d_counts, (size_t)c->n_samples * 4 + 256);
+    delete c;
+}
+
+uint64_t tgx_corpus_num_samples(const tgx_corpus* c) { return c ? c->n_samples : 0; }
+uint64_t tgx_corpus_num_bytes(const tgx_corpus* c) { return c ? c->n_bytes : 0; }
+
+// ---- encode --------------------------------------------------------------------
+
+tgx_status tgx_encode_corpus(tgx_model* m, tgx_corpus* c, double dropout, uint64_t seed,
+                             tgx_result** out) {
+    if (!m || !c || !out) return fail(TGX_ERR_INVALID, "tgx_encode_corpus: NULL argument");
+    *out = nullptr;
+    if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    m->n_timed = 0;
+    const uint64_t S = c->n_samples;
+
+    tgx_result* r = new tgx_result();
+    r->device = m->device;
+    r->n_samples = S;
+    auto cleanup = [&](tgx_status st) {
+        tgx_result_free(r);
+        return st;
+    };
+    if (pool_alloc(m->device, (size_t)(S + 1) * 8, (void**)&r->d_offs) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (result offsets)"));
+
+    tgx_status st = run_encode_kernel(m, c, tgx::MODE_ENCODE, dropout, seed, nullptr);
+    if (st != TGX_OK) return cleanup(st);
+    time_begin(m, "scan_counts_kernel");
+    if (tgx::launch_scan(c->d_counts, r->d_offs, S, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "scan launch failed"));
+    time_end(m);
+    if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(&m->h_ctrl[1], r->d_offs + S, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "encode pass failed: %s", hipGetErrorString(hipGetLastError())));
+    st = check_no_path(m, c);
+    if (st != TGX_OK) return cleanup(st);
+
+    r->n_tokens = m->h_ctrl[1];
+    if (pool_alloc(m->device, (size_t)r->n_tokens * 4 + 256, (void**)&r->d_ids) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (result ids)"));
+    if (hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "memset failed"));
+    tgx::CompactParams cp{};
+    cp.offs = c->d_offs;
+    cp.order = c->d_order;
+    cp.n_samples = S;
+    cp.tmp = c->d_tmp;
+    cp.out_offs = r->d_offs;
+    cp.ids = r->d_ids;
+    cp.next = m->d_ctrl;
+    time_begin(m, "compact_kernel");
+    uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((S + 3) / 4, (uint64_t)m->num_cus * 8));
+    if (tgx::launch_compact(cp, blocks, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "compact launch failed"));
+    time_end(m);
+    if (hipStreamSynchronize(m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "compact failed: %s", hipGetErrorString(hipGetLastError())));
+    // N + 4T + 16(S+1)
+    m->last_alg_bytes = c->n_bytes + 4 * r->n_tokens + 16 * (S + 1);
+    *out = r;
+    return TGX_OK;
+}
+
+tgx_status tgx_encode_batch(tgx_model* m, const uint8_t* text, const uint64_t* offs,
+                            uint64_t n_samples, double dropout, uint64_t seed, tgx_result** out) {
+    if (!m || !out) return fail(TGX_ERR_INVALID, "tgx_encode_batch: NULL argument");
+    *out = nullptr;
+    tgx_corpus* c = nullptr;
+    tgx_status st = tgx_corpus_upload(m->device, text, offs, n_samples, &c);
+    if (st != TGX_OK) return st;
+    st = tgx_encode_corpus(m, c, dropout, seed, out);
+    tgx_corpus_free(c);
+    return st;
+}
+
+uint64_t tgx_result_num_samples(const tgx_result* r) { return r ? r->n_samples : 0; }
+uint64_t tgx_result_num_tokens(const tgx_result* r) { return r ? r->n_tokens : 0; }
+
+const uint32_t* tgx_result_ids(tgx_result* r) {
+    if (!r) return nullptr;
+    if (!r->have_ids) {
+        r->h_ids.resize(r->n_tokens ? r->n_tokens : 1);
+        if (r->n_tokens) {
+            (void)hipSetDevice(r->device);
+            if (hipMemcpy(r->h_ids.data(), r->d_ids, r->n_tokens * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                fail(TGX_ERR_DEVICE, "D2H copy of ids failed");
+                return nullptr;
+            }
+        }
+        r->have_ids = true;
+    }
+    return r->h_ids.data();
+}
+
+const uint64_t* tgx_result_offsets(tgx_result* r) {
+    if (!r) return nullptr;
+    if (!r->have_offs) {
+        r->h_offs.resize(r->n_samples + 1);
+        (void)hipSetDevice(r->device);
+        if (hipMemcpy(r->h_offs.data(), r->d_offs, (r->n_samples + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+            fail(TGX_ERR_DEVICE, "D2H copy of offsets failed");
+            return nullptr;
+        }
+        r->have_offs = true;
+    }
+    return r->h_offs.data();
+}
+
+const void* tgx_result_ids_device(const tgx_result* r) { return r ? r->d_ids : nullptr; }
+const void* tgx_result_offsets_device(const tgx_result* r) { return r ? r->d_offs : nullptr; }
+
+void tgx_result_free(tgx_result* r) {
+    if (!r) return;
+    pool_free(r->device, r->d_ids, (size_t)r->n_tokens * 4 + 256);
+    pool_free(r->device, r->d_offs, (size_t)(r->n_samples + 1) * 8);
+    delete r;
+}
+
+// ---- frequency pass ------------------------------------------------------------
+
+tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
+    if (!m || !c || !freq) return fail(TGX_ERR_INVALID, "tgx_count_tokens: NULL argument");
+    if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    m->n_timed = 0;
+    const size_t fbytes = (size_t)m->vocab_size * 8 + 256;
+    unsigned long long* d_freq = nullptr;
+    HIP_TRY(pool_alloc(m->device, fbytes, (void**)&d_freq));
+    auto cleanup = [&](tgx_status st) {
+        pool_free(m->device, d_freq, fbytes);
+        return st;
+    };
+    if (hipMemsetAsync(d_freq, 0, fbytes, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "memset failed"));
+    tgx_status st = run_encode_kernel(m, c, tgx::MODE_COUNT, 0.0, 0, d_freq);
+    if (st != TGX_OK) return cleanup(st);
+    std::vector<unsigned long long> h(m->vocab_size ? m->vocab_size : 1);
+    if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(h.data(), d_freq, (size_t)m->vocab_size * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "count pass failed: %s", hipGetErrorString(hipGetLastError())));
+    st = check_no_path(m, c);
+    if (st != TGX_OK) return cleanup(st);
+    for (uint32_t i = 0; i < m->vocab_size; i++) freq[i] += h[i];
+    m->last_alg_bytes = c->n_bytes + 8 * (c->n_samples + 1) + 8ull * m->vocab_size;
+    return cleanup(TGX_OK);
+}
+
+tgx_status tgx_count_pairs(tgx_model* m, tgx_corpus* c, uint64_t** keys, uint64_t** counts,
+                           uint64_t* n_pairs) {
+    (void)m; (void)c; (void)keys; (void)counts; (void)n_pairs;
+    return fail(TGX_ERR_UNSUPPORTED, "tgx_count_pairs: not implemented yet");
+}
+
+tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout,
+                     uint64_t seed, double* expected, double* logz_sum) {
+    (void)m; (void)c; (void)snippet_len; (void)dropout; (void)seed; (void)expected; (void)logz_sum;
+    return fail(TGX_ERR_UNSUPPORTED, "tgx_estep: not implemented yet");
+}
+
+// ---- measurement ---------------------------------------------------------------
+
+int tgx_last_kernel_times(const tgx_model* m, const char** names, float* ms, int cap) {
+    if (!m) return 0;
+    int n = 0;
+    for (int i = 0; i < m->n_timed && n < cap; i++) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, m->timed[i].start, m->timed[i].stop) != hipSuccess) t = -1.f;
+        if (names) names[n] = m->timed[i].name;
+        if (ms) ms[n] = t;
+        n++;
+    }
+    return n;
+}
+
+uint64_t tgx_last_algorithmic_bytes(const tgx_model* m) { return m ? m->last_alg_bytes : 0; }
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+#include "trie_build.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace tgx {
+
+namespace {
+
+struct Edge {
+    uint32_t parent;
+    uint32_t child;
+    uint8_t byte;
+};
+
+// (parent node, byte) -> child node, open addressing.
+struct EdgeMap {
+    std::vector<uint64_t> keys;  // key + 1, 0 = empty
+    std::vector<uint32_t> vals;
+    uint64_t mask = 0, count = 0;
+
+    static uint64_t mix(uint64_t x) {
+        x ^= x >> 33;
+        x *= 0xff51afd7ed558ccdULL;
+        x ^= x >> 33;
+        x *= 0xc4ceb9fe1a85ec53ULL;
+        x ^= x >> 33;
+        return x;
+    }
+    void reserve(uint64_t n) {
+        uint64_t cap = 1024;
+        while (cap < n * 2) cap <<= 1;
+        keys.assign(cap, 0);
+        vals.assign(cap, 0);
+        mask = cap - 1;
+        count = 0;
+    }
+    // returns child index; creates it (value = next) when absent
+    uint32_t get_or_insert(uint64_t key, uint32_t next, bool* created) {
+        uint64_t i = mix(key) & mask;
+        for (;;) {
+            if (keys[i] == 0) {
+                keys[i] = key + 1;
+                vals[i] = next;
+                count++;
+                *created = true;
+                return next;
+            }
+            if (keys[i] == key + 1) {
+                *created = false;
+                return vals[i];
+            }
+            i = (i + 1) & mask;
+        }
+    }
+};
+
+struct BlockAlloc {
+    std::vector<uint64_t> used;      // 4 words per 256-slot block
+    std::vector<uint16_t> free_cnt;  // per block
+    uint32_t head1 = 0;              // first block that may have a free slot
+    uint32_t headk = 0;              // first block worth trying for multi-child nodes
+
+    uint32_t n_blocks() const { return (uint32_t)free_cnt.size(); }
+    void add_block() {
+        used.insert(used.end(), 4, 0ULL);
+        free_cnt.push_back(256);
+    }
+    bool is_used(uint32_t t) const { return (used[t >> 6] >> (t & 63)) & 1ULL; }
+    void mark(uint32_t t) {
+        used[t >> 6] |= 1ULL << (t & 63);
+        free_cnt[t >> 8]--;
+    }
+    int first_free_in_block(uint32_t b) const {
+        for (int w = 0; w < 4; w++) {
+            uint64_t inv = ~used[(size_t)b * 4 + w];
+            if (inv) return w * 64 + __builtin_ctzll(inv);
+        }
+        return -1;
+    }
+};
+
+}  // namespace
+
+void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* scores,
+                     uint32_t vocab_size, FlatTrie* out) {
+    // 1. pointer-free trie: nodes are indices, edges in a hash map.
+    uint64_t total_bytes = vocab_size ? offs[vocab_size] - offs[0] : 0;
+    EdgeMap em;
+    em.reserve(total_bytes + 16);
+    std::vector<Edge> edges;
+    edges.reserve(total_bytes / 2 + 16);
+    std::vector<uint32_t> node_tok(1, kNoToken);  // node 0 = root
+    uint32_t max_len = 0;
+    for (uint32_t id = 0; id < vocab_size; id++) {
+        uint64_t b = offs[id], e = offs[id + 1];
+        if (e == b) continue;  // empty token: root payload, never matched
+        uint32_t node = 0;
+        for (uint64_t i = b; i < e; i++) {
+            bool created;
+            uint32_t nxt = em.get_or_insert(((uint64_t)node << 8) | bytes[i], (uint32_t)node_tok.size(),
+                                            &created);
+            if (created) {
+                node_tok.push_back(kNoToken);
+                edges.push_back(Edge{node, nxt, bytes[i]});
+            }
+            node = nxt;
+        }
+        node_tok[node] = id;  // overwrite: the last duplicate wins
+        max_len = std::max<uint32_t>(max_len, (uint32_t)(e - b));
+    }
+    uint32_t n_nodes = (uint32_t)node_tok.size();
+
+    // 2. children in CSR form, sorted by (parent, byte).
+    std::sort(edges.begin(), edges.end(), [](const Edge& a, const Edge& b) {
+        return a.parent != b.parent ? a.parent < b.parent : a.byte < b.byte;
+    });
+    std::vector<uint32_t> row(n_nodes + 1, 0);
+    for (const Edge& e : edges) row[e.parent + 1]++;
+    for (uint32_t i = 0; i < n_nodes; i++) row[i + 1] += row[i];
+
+    // 3. breadth-first slot assignment (hot top levels land in the first blocks).
+    BlockAlloc ba;
+    ba.add_block();
+    ba.mark(0);  // root
+    std::vector<uint32_t> slot(n_nodes, 0), base(n_nodes, 0);
+    std::vector<uint32_t> queue;
+    queue.reserve(n_nodes);
+    queue.push_back(0);
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        uint32_t node = queue[qi];
+        uint32_t lo = row[node], hi = row[node + 1], k = hi - lo;
+        if (k == 0) continue;
+        uint32_t chosen = 0;
+        bool found = false;
+        if (k == 1) {
+            while (ba.head1 < ba.n_blocks() && ba.free_cnt[ba.head1] == 0) ba.head1++;
+            if (ba.head1 == ba.n_blocks()) ba.add_block();
+            uint32_t b = ba.head1;
+            int f = ba.first_free_in_block(b);
+            chosen = (b << 8) | ((uint32_t)f ^ edges[lo].byte);
+            found = true;
+        } else {
+            while (ba.headk < ba.n_blocks() && ba.free_cnt[ba.headk] < 24) ba.headk++;
+            uint32_t tried = 0;
+            for (uint32_t b = ba.headk; b < ba.n_blocks() && tried < 24 && !found; b++) {
+                if (ba.free_cnt[b] < k) continue;
+                tried++;
+                const uint64_t* u = &ba.used[(size_t)b * 4];
+                for (uint32_t x = 0; x < 256 && !found; x++) {
+                    bool ok = true;
+                    for (uint32_t j = lo; j < hi; j++) {
+                        uint32_t t = x ^ edges[j].byte;
+                        if ((u[t >> 6] >> (t & 63)) & 1ULL) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                    if (ok) {
+                        chosen = (b << 8) | x;
+                        found = true;
+                    }
+                }
+            }
+            if (!found) {
+                ba.add_block();
+                chosen = (ba.n_blocks() - 1) << 8;
+                found = true;
+            }
+        }
+        base[node] = chosen;
+        for (uint32_t j = lo; j < hi; j++) {
+            uint32_t t = chosen ^ edges[j].byte;
+            ba.mark(t);
+            slot[edges[j].child] = t;
+            queue.push_back(edges[j].child);
+        }
+    }
+
+    // 4. records.
+    uint32_t n_slots = ba.n_blocks() * 256;
+    out->table.assign(n_slots, TrieRec{kNoParent, 0, 0});
+    out->tokid.assign(n_slots, kNoToken);
+    out->table[0].base = base[0];
+    for (const Edge& e : edges) {
+        uint32_t t = slot[e.child];
+        TrieRec& r = out->table[t];
+        r.check = slot[e.parent];
+        r.base = base[e.child];
+        uint32_t id = node_tok[e.child];
+        if (id != kNoToken) {
+            r.base |= kTerminalBit;
+            std::memcpy(&r.score_bits, &scores[id], 8);
+            out->tokid[t] = id;
+        }
+    }
+    out->max_token_len = max_len;
+    out->n_nodes = n_nodes;
+}
+
+uint64_t flat_common_prefix_search(const FlatTrie& t, const uint8_t* s, uint64_t n, uint32_t* ids,
+                                   uint32_t* lens, uint64_t cap) {
+    uint32_t cur = 0, base = t.table[0].base & ~kTerminalBit;
+    uint64_t found = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t nxt = base ^ s[i];
+        const TrieRec& r = t.table[nxt];
+        if (r.check != cur) break;
+        cur = nxt;
+        base = r.base & ~kTerminalBit;
+        if (r.base & kTerminalBit) {
+            if (found < cap) {
+                ids[found] = t.tokid[nxt];
+                lens[found] = (uint32_t)(i + 1);
+            }
+            found++;
+        }
+    }
+    return found;
+}
+
+}  // namespace tgx

@@ -1,0 +1,48 @@
+// Flattened byte trie: XOR double-array, the HBM-resident replacement of the
+// reference's pointer/HashMap trie (reference src/trie.rs:7-87, built by
+// Model::from, src/model.rs:16-30).
+//
+// One 16-byte record per slot t:
+//   x = check  : slot of the parent node (0xFFFFFFFF = unused slot / root)
+//   y = base   : children of this node live at slot (base ^ byte); bit 31 set
+//                when this node is terminal (a vocabulary token ends here)
+//   z,w = score: f64 bits of vocab[id].score for terminal nodes
+// Child of node s by byte c is t = base[s] ^ c, valid iff check[t] == s, so one
+// 16-byte gather per trie step, and all children of a node share one 256-slot
+// (4 KiB) block.  The root is slot 0.  tokid[t] gives the token id of a
+// terminal slot (read once per emitted token, not per match).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace tgx {
+
+struct TrieRec {
+    uint32_t check;
+    uint32_t base;  // bit 31: terminal
+    uint64_t score_bits;
+};
+static_assert(sizeof(TrieRec) == 16, "TrieRec must be 16 bytes");
+
+constexpr uint32_t kTerminalBit = 0x80000000u;
+constexpr uint32_t kNoParent = 0xFFFFFFFFu;
+constexpr uint32_t kNoToken = 0xFFFFFFFFu;
+
+struct FlatTrie {
+    std::vector<TrieRec> table;   // n_slots records (multiple of 256)
+    std::vector<uint32_t> tokid;  // n_slots, kNoToken when not terminal
+    uint32_t max_token_len = 0;
+    uint32_t n_nodes = 0;
+};
+
+// Model::from: token i = bytes[offs[i]..offs[i+1]), id = i; a later duplicate
+// overwrites the payload of an earlier one (src/trie.rs:19); empty tokens are
+// stored on the root and can never match (src/trie.rs:53-61), so they are skipped.
+void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* scores,
+                     uint32_t vocab_size, FlatTrie* out);
+
+// Host twin of the device walk (TrieIterator::next, src/trie.rs:51-63).
+uint64_t flat_common_prefix_search(const FlatTrie& t, const uint8_t* s, uint64_t n, uint32_t* ids,
+                                   uint32_t* lens, uint64_t cap);
+
+}  // namespace tgx

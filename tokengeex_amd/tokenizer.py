@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference's `Tokenizer` (src/tokenizer.rs:6-435) and of
+its PyO3 surface (bindings/python/src/lib.rs:41-223, tokengeex.pyi:10-255).
+
+Same method names, argument order and error strings as the PyO3 class; the hot
+path (Model::encode over a batch) goes through the C ABI to the HIP kernels, the
+rest (special-token splitting, processors, decode, JSON) is host glue in Python.
+"""
+from __future__ import annotations
+
+import base64
+import json
+import random
+import re
+import unicodedata
+
+import numpy as np
+
+from . import _lib
+from ._lib import TokenGeeXError
+
+SERIALIZATION_VERSION = "2.0"  # src/tokenizer.rs:347
+
+
+# ---- processors: src/processor.rs ---------------------------------------------
+
+class CrlfProcessor:
+    """src/processor.rs:37-54: plain "\\r\\n" -> "\\n"; postprocess is identity."""
+
+    def preprocess(self, s: str) -> str:
+        return s.replace("\r\n", "\n")
+
+    def postprocess(self, s: str) -> str:
+        return s
+
+    def to_json(self):
+        return {"type": "crlf"}
+
+
+class UnicodeProcessor:
+    """src/processor.rs:124-137.  The reference delegates to the
+    unicode-normalization crate; here unicodedata does the same UAX #15 forms
+    (parity with the crate's Unicode version is not pinned by any reference test)."""
+
+    FORMS = {"nfc": "NFC", "nfd": "NFD", "nfkc": "NFKC", "nfkd": "NFKD"}
+
+    def __init__(self, form: str):
+        if form not in self.FORMS:
+            raise TokenGeeXError(f"unknown variant `{form}`, expected one of `nfc`, `nfd`, `nfkc`, `nfkd`",
+                                 _lib.ERR_JSON)
+        self.form = form
+
+    def preprocess(self, s: str) -> str:
+        return unicodedata.normalize(self.FORMS[self.form], s)
+
+    def postprocess(self, s: str) -> str:
+        return s
+
+    def to_json(self):
+        return {"type": "unicode", "form": self.form}
+
+
+def _processor_from_json(obj):
+    # untagged enum, src/processor.rs:13-18: Crlf is tried first, then Unicode
+    if not isinstance(obj, dict):
+        raise TokenGeeXError("data did not match any variant of untagged enum ProcessorWrapper", _lib.ERR_JSON)
+    if obj.get("type") == "crlf" and "form" not in obj:
+        return CrlfProcessor()
+    if "form" in obj:
+        return UnicodeProcessor(obj["form"])
+    raise TokenGeeXError("data did not match any variant of untagged enum ProcessorWrapper", _lib.ERR_JSON)
+
+
+# ---- special token splitter: src/tokenizer.rs:299-347 ------------------------------
+
+def split_special_tokens(text: str, special_tokens: list[str]) -> list[tuple[str, bool]]:
+    """Earliest char position wins; at one position the first special in list order
+    wins (not the longest).  A regex alternation has exactly these semantics."""
+    if not text:
+        return []
+    if not special_tokens:
+        return [(text, False)]
+    pat = re.compile("|".join(re.escape(t) for t in special_tokens))
+    out, cursor = [], 0
+    for mt in pat.finditer(text):
+        if mt.start() > cursor:
+            out.append((text[cursor:mt.start()], False))
+        out.append((mt.group(0), True))
+        cursor = mt.end()
+    if cursor < len(text):
+        out.append((text[cursor:], False))
+    return out
+
+
+# ---- Tokenizer ---------------------------------------------------------------------
+
+class Tokenizer:
+    """tokengeex.Tokenizer (bindings/python/src/lib.rs:11-224)."""
+
+    def __init__(self, vocab: list[tuple[bytes, float, bool]] | None = None, processors=None,
+                 special_tokens=None, device: int = 0):
+        # Model: src/model.rs:8-12
+        self._vocab: list[tuple[bytes, float, bool]] = [(bytes(v), float(s), bool(k)) for v, s, k in (vocab or [])]
+        self._token_to_ids: dict[bytes, int] = {}
+        for i, (v, _, _) in enumerate(self._vocab):
+            self._token_to_ids[v] = i  # later duplicates overwrite, src/model.rs:21
+        self._processors = list(processors or [])
+        self._special_tokens: list[str] = []
+        self._special_tokens_map: dict[str, int] = {}
+        self._device = device
+        self._native: _lib.NativeModel | None = None
+        self.seed: int | None = None  # dropout seed; None = fresh random seed per call
+        self.add_special_tokens(list(special_tokens or []))
+
+    # -- native model (lazy: building it needs the GPU) --
+    def _model(self) -> _lib.NativeModel:
+        if self._native is None:
+            self._native = _lib.NativeModel([v for v, _, _ in self._vocab],
+                                            np.array([s for _, s, _ in self._vocab], dtype=np.float64),
+                                            self._device)
+        return self._native
+
+    def _seed(self, dropout: float) -> int:
+        if dropout <= 0.0:
+            return 0
+        return self.seed if self.seed is not None else random.getrandbits(64)
+
+    def _preprocess(self, s: str) -> str:
+        for p in self._processors:  # src/tokenizer.rs:79-82
+            s = p.preprocess(s)
+        return s
+
+    # -- encode: src/tokenizer.rs:65-123 --
+    def encode(self, text: str, dropout: float) -> list[int]:
+        return self.encode_batch([text], dropout)[0]
+
+    def encode_ordinary(self, text: str, dropout: float) -> list[int]:
+        return self.encode_ordinary_batch([text], dropout)[0]
+
+    def encode_ordinary_batch(self, texts: list[str], dropout: float) -> list[list[int]]:
+        segs = [self._preprocess(t).encode("utf-8") for t in texts]
+        ids, offs = self._encode_segments(segs, dropout)
+        return [ids[int(offs[i]):int(offs[i + 1])].tolist() for i in range(len(texts))]
+
+    def encode_batch(self, texts: list[str], dropout: float) -> list[list[int]]:
+        if not self._special_tokens:
+            return self.encode_ordinary_batch(texts, dropout)
+        base = self.base_vocab_size()
+        plan, segs = [], []  # per text: list of (special id | -1)
+        for t in texts:
+            row = []
+            for sub, is_special in split_special_tokens(t, self._special_tokens):
+                if is_special:
+                    row.append(base + self._special_tokens_map[sub])  # src/tokenizer.rs:70-77
+                else:
+                    row.append(-1)
+                    segs.append(self._preprocess(sub).encode("utf-8"))
+            plan.append(row)
+        ids, offs = self._encode_segments(segs, dropout)
+        out, k = [], 0
+        for row in plan:
+            cur: list[int] = []
+            for item in row:
+                if item >= 0:
+                    cur.append(item)
+                else:
+                    cur.extend(ids[int(offs[k]):int(offs[k + 1])].tolist())
+                    k += 1
+            out.append(cur)
+        return out
+
+    def _encode_segments(self, segs: list[bytes], dropout: float):
+        if not segs:
+            return np.zeros(0, np.uint32), np.zeros(1, np.uint64)
+        flat, offs = _lib.pack(segs)
+        return self.encode_ordinary_batch_flat(flat, offs, dropout)
+
+    def encode_ordinary_batch_flat(self, flat: np.ndarray, offs: np.ndarray, dropout: float = 0.0):
+        """Flat-buffer entry point the reference lacks: packed bytes + offsets in,
+        (ids uint32[T], offsets uint64[S+1]) out, no per-sample Python objects."""
+        res = self._model().encode_batch_flat(flat, offs, dropout, self._seed(dropout))
+        try:
+            return res.ids(), res.offsets()
+        finally:
+            res.free()
+
+    # -- decode: src/tokenizer.rs:126-187, src/model.rs:146-160 --
+    def _model_decode(self, ids) -> str:
+        buf = bytearray()
+        n = len(self._vocab)
+        for i in ids:
+            if i >= n:
+                raise TokenGeeXError(f"token id {i} is out of bounds", _lib.ERR_TOKEN_ID_OOB)
+            buf += self._vocab[i][0]
+        return bytes(buf).decode("utf-8", "replace")  # String::from_utf8_lossy
+
+    def _postprocess(self, s: str) -> str:
+        for p in reversed(self._processors):
+            s = p.postprocess(s)
+        return s
+
+    def decode(self, ids: list[int], include_special_tokens: bool) -> str:
+        n = len(self._vocab)
+        out, run = [], []
+        for i in ids:
+            if i >= n:
+                out.append(self._postprocess(self._model_decode(run)))
+                run = []
+                k = i - n
+                if k >= len(self._special_tokens):
+                    raise TokenGeeXError(f"token id {i} is out of bounds", _lib.ERR_TOKEN_ID_OOB)
+                if include_special_tokens:
+                    out.append(self._special_tokens[k])
+            else:
+                run.append(i)
+        out.append(self._postprocess(self._model_decode(run)))
+        return "".join(out)
+
+    def decode_batch(self, ids: list[list[int]], include_special_tokens: bool) -> list[str]:
+        return [self.decode(x, include_special_tokens) for x in ids]
+
+    # -- id / token queries: src/tokenizer.rs:189-259 --
+    def token_to_id(self, token: bytes) -> int | None:
+        r = self.base_token_to_id(token)
+        if r is not None:
+            return r
+        try:
+            return self.special_token_to_id(bytes(token).decode("utf-8"))
+        except UnicodeDecodeError:
+            return None
+
+    def base_token_to_id(self, token: bytes) -> int | None:
+        return self._token_to_ids.get(bytes(token))
+
+    def special_token_to_id(self, token: str) -> int | None:
+        k = self._special_tokens_map.get(token)
+        return None if k is None else k + len(self._vocab)
+
+    def id_to_token(self, id: int) -> bytes | None:
+        s = self.id_to_special_token(id)
+        if s is not None:
+            return s.encode("utf-8")
+        b = self.id_to_base_token(id)
+        return None if b is None else b[0]
+
+    def id_to_base_token(self, id: int) -> tuple[bytes, float] | None:
+        if 0 <= id < len(self._vocab):
+            return self._vocab[id][0], self._vocab[id][1]
+        return None
+
+    def id_to_special_token(self, id: int) -> str | None:
+        k = id - len(self._vocab)
+        if 0 <= k < len(self._special_tokens):
+            return self._special_tokens[k]
+        return None
+
+    def is_special(self, id: int) -> bool:
+        return self.id_to_special_token(id) is not None
+
+    def is_base(self, id: int) -> bool:
+        return id < len(self._vocab)
+
+    def add_special_tokens(self, tokens: list[str]) -> None:
+        for t in tokens:  # src/tokenizer.rs:39-53: existing specials are ignored
+            if t == "":
+                raise ValueError("empty special token (the reference's splitter would never advance)")
+            if t in self._special_tokens_map:
+                continue
+            self._special_tokens_map[t] = len(self._special_tokens)
+            self._special_tokens.append(t)
+
+    def add_base_tokens(self, tokens: list[tuple[bytes, float, bool]]) -> None:
+        """Tokenizer::add_base_tokens -> Model::add_tokens, src/model.rs:184-194."""
+        for v, s, k in tokens:
+            self._token_to_ids[bytes(v)] = len(self._vocab)
+            self._vocab.append((bytes(v), float(s), bool(k)))
+        if self._native is not None:  # mutation = build a new device handle
+            self._native.free()
+            self._native = None
+
+    def special_tokens(self) -> list[str]:
+        return list(self._special_tokens)
+
+    def vocab_size(self) -> int:
+        return len(self._vocab) + len(self._special_tokens)
+
+    def base_vocab_size(self) -> int:
+        return len(self._vocab)
+
+    def special_vocab_size(self) -> int:
+        return len(self._special_tokens)
+
+    def common_prefix_search(self, text: str) -> list[int]:
+        return [i for i, _ in self._model().common_prefix_search(text.encode("utf-8"))]
+
+    # -- serialisation: src/tokenizer.rs:261-297, 349-435, src/lib.rs:109-204 --
+    def to_string(self) -> str:
+        vocab = []
+        for v, s, k in self._vocab:
+            try:
+                e = {"value": v.decode("utf-8"), "score": s}
+            except UnicodeDecodeError:
+                e = {"value": base64.b64encode(v).decode("ascii").rstrip("="), "score": s, "encoded": True}
+            if k:
+                e["keep"] = True
+            vocab.append(e)
+        return json.dumps({"version": SERIALIZATION_VERSION, "special_tokens": self._special_tokens,
+                           "processors": [p.to_json() for p in self._processors], "vocab": vocab},
+                          ensure_ascii=False, separators=(",", ":"))
+
+    def save(self, filename: str) -> None:
+        with open(filename, "w", encoding="utf-8") as f:
+            f.write(self.to_string())
+
+    @staticmethod
+    def from_str(data: str, device: int = 0) -> "Tokenizer":
+        try:
+            obj = json.loads(data)
+        except json.JSONDecodeError as e:
+            raise TokenGeeXError(str(e), _lib.ERR_JSON) from None
+        if not isinstance(obj, dict):
+            raise TokenGeeXError("invalid type: expected struct Tokenizer", _lib.ERR_JSON)
+        allowed = ("version", "special_tokens", "processors", "vocab")
+        for key in obj:
+            if key not in allowed:  # src/tokenizer.rs:414-419
+                raise TokenGeeXError(f"unknown field `{key}`, expected one of `version`, `special_tokens`, "
+                                     "`processors`, `vocab`", _lib.ERR_JSON)
+        if "version" not in obj:
+            raise TokenGeeXError("missing field `version`", _lib.ERR_JSON)
+        if obj["version"] != SERIALIZATION_VERSION:  # src/tokenizer.rs:423-429
+            raise TokenGeeXError(f"unsupported version: {obj['version']}", _lib.ERR_JSON)
+        vocab = []
+        for e in obj.get("vocab", []):
+            for key in e:
+                if key not in ("value", "score", "encoded", "keep"):  # src/lib.rs:173-175
+                    raise TokenGeeXError(f"unknown field `{key}`, expected one of `value`, `score`, "
+                                         "`encoded`, `keep`", _lib.ERR_JSON)
+            if "value" not in e:
+                raise TokenGeeXError("missing field `token`", _lib.ERR_JSON)  # sic, src/lib.rs:189
+            if "score" not in e:
+                raise TokenGeeXError("missing field `score`", _lib.ERR_JSON)
+            if e.get("encoded", False):
+                v = e["value"]
+                raw = base64.b64decode(v + "=" * (-len(v) % 4))  # STANDARD_NO_PAD, src/lib.rs:8
+            else:
+                raw = e["value"].encode("utf-8")
+            vocab.append((raw, float(e["score"]), bool(e.get("keep", False))))
+        procs = [_processor_from_json(p) for p in obj.get("processors", [])]
+        return Tokenizer(vocab, procs, obj.get("special_tokens", []), device=device)
+
+    @staticmethod
+    def from_file(filepath: str, device: int = 0) -> "Tokenizer":
+        try:
+            with open(filepath, encoding="utf-8") as f:
+                data = f.read()
+        except OSError as e:
+            raise TokenGeeXError(str(e), _lib.ERR_IO) from None
+        return Tokenizer.from_str(data, device=device)
+
+    def __getstate__(self):
+        return self.to_string().encode("utf-8")
+
+    def __setstate__(self, state):
+        other = Tokenizer.from_str(bytes(state).decode("utf-8"))
+        self.__dict__.update(other.__dict__)
+
+    # -- access for the training-loop entry points --
+    def vocab(self) -> list[tuple[bytes, float, bool]]:
+        return list(self._vocab)
+
+    def native_model(self) -> _lib.NativeModel:
+        return self._model()
