@@ -80,14 +80,14 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
     const bool use_dropout = P.dropout > 0.0;
 
-    for (;;) {
-        unsigned long long k = 0;
-        if (lane == 0) k = atomicAdd(P.next, 1ULL);
-        k = first_u64(k);
-        if (k >= P.n_samples) break;  // every wave reaches this: the counter only grows
-        const uint32_t s = P.order[k];
-        const uint64_t beg = P.offs[s];
-        const uint32_t n = (uint32_t)(P.offs[s + 1] - beg);
+    // Static round-robin over the longest-first order: wave w takes samples w, w + W,
+    // w + 2W, ...  (no work queue: every wave's trip count is known at launch).
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wave));
+    for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
+        const uint64_t beg = first_u64(P.offs[s]);
+        const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
         const uint8_t* __restrict__ text = P.text + beg;
         uint32_t* __restrict__ bp = P.bp + beg;  // bp[e - 1] for end position e in 1..n
 
@@ -168,19 +168,12 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
             if (e >= 1 && e <= n) bp[e - 1] = fin;
         }
 
-        if (!reach_n) {  // Error::NoPath(n, n), model.rs:119
-            if (lane == 0) {
-                atomicMin(P.err_sample, (unsigned long long)s);
-                P.counts[s] = 0;
-            }
-            continue;
-        }
-
         // ---- trace: follow the back-pointers from n (model.rs:113-126), 64 positions per hop group
         __threadfence_block();  // this wave's bp stores above are read back below
         uint32_t total = 0;
         uint64_t cursor = beg + n;  // one past this sample's slice of tmp
-        int64_t q = (int64_t)n - 1; // index into bp of the current end position
+        // Error::NoPath(n, n), model.rs:119: nothing to trace, the sample is reported below
+        int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // index into bp of the current end position
         while (q >= 0) {
             const uint32_t wq = (uint32_t)q & ~63u;
             const uint32_t idx = wq + lane;
@@ -206,7 +199,10 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
             cursor -= cnt;
             total += cnt;
         }
-        if (lane == 0) P.counts[s] = total;
+        if (lane == 0) {
+            P.counts[s] = total;
+            if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);
+        }
     }
 }
 
@@ -243,11 +239,9 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __res
 // tmp (right-aligned per sample) -> ids (packed), one wave per sample.
 __global__ __launch_bounds__(256) void compact_kernel(CompactParams P) {
     const uint32_t lane = threadIdx.x & 63u;
-    for (;;) {
-        unsigned long long k = 0;
-        if (lane == 0) k = atomicAdd(P.next, 1ULL);
-        k = first_u64(k);
-        if (k >= P.n_samples) break;
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
         const uint32_t s = P.order[k];
         const uint64_t end = P.offs[s + 1];
         const uint64_t o0 = P.out_offs[s];

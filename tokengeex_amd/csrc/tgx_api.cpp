@@ -156,7 +156,22 @@ int usable_device_count() {
     return n;
 }
 
+// TGX_DEBUG=1: log every launch to stderr and synchronise after it, so that a
+// device fault can be attributed to one kernel.
+bool debug_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TGX_DEBUG");
+        v = (e && *e && *e != '0') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 void time_begin(tgx_model* m, const char* name) {
+    if (debug_on()) {
+        fprintf(stderr, "[tgx] launch %s\n", name);
+        fflush(stderr);
+    }
     if (m->n_timed >= kMaxTimed) return;
     KernelTime& t = m->timed[m->n_timed];
     t.name = name;
@@ -164,6 +179,11 @@ void time_begin(tgx_model* m, const char* name) {
     (void)hipEventRecord(t.start, m->stream);
 }
 void time_end(tgx_model* m) {
+    if (debug_on()) {
+        hipError_t e = hipStreamSynchronize(m->stream);
+        fprintf(stderr, "[tgx]   done: %s\n", hipGetErrorString(e));
+        fflush(stderr);
+    }
     if (m->n_timed >= kMaxTimed) return;
     (void)hipEventRecord(m->timed[m->n_timed].stop, m->stream);
     m->n_timed++;
@@ -209,6 +229,11 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     p.err_sample = m->d_ctrl + 1;
     p.dropout = dropout;
     p.seed = seed;
+    if (debug_on())
+        fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u blocks=%u lds=%u slots=%zu root_base=%u\n",
+                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm,
+                grid_blocks(m, mode, c->n_samples), tgx::encode_lds_bytes_per_block(p.lm),
+                m->flat.table.size(), p.root_base);
     time_begin(m, mode == tgx::MODE_ENCODE ? "encode_kernel" : "encode_count_kernel");
     HIP_TRY(tgx::launch_encode(p, mode, grid_blocks(m, mode, c->n_samples), m->stream));
     time_end(m);
