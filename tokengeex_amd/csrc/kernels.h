@@ -37,6 +37,7 @@ struct CompactParams {
 };
 
 uint32_t encode_lds_bytes_per_block(uint32_t lm);
+uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out);
 hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);

@@ -82,8 +82,9 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
 
     // Static round-robin over the longest-first order: wave w takes samples w, w + W,
     // w + 2W, ...  (no work queue: every wave's trip count is known at launch).
-    const uint32_t n_waves = gridDim.x * 4u;
-    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + wave));
+    const uint32_t wpb = blockDim.x >> 6;  // waves per block: 4 for short tokens, fewer when LDS-bound
+    const uint32_t n_waves = gridDim.x * wpb;
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + wave));
     for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
         const uint64_t beg = first_u64(P.offs[s]);
@@ -254,31 +255,38 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams P) {
 
 // ---- launchers -------------------------------------------------------------
 
-uint32_t encode_lds_bytes_per_block(uint32_t lm) { return 4u * wave_lds_bytes(lm); }
+// Waves per block: as many (<= 4) as keep one block's LDS within 64 KiB.
+uint32_t encode_waves_per_block(uint32_t lm) {
+    uint32_t w = (64u * 1024u) / wave_lds_bytes(lm);
+    return w < 1u ? 1u : (w > 4u ? 4u : w);
+}
+uint32_t encode_lds_bytes_per_block(uint32_t lm) { return encode_waves_per_block(lm) * wave_lds_bytes(lm); }
 
 hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream) {
     const uint32_t lds = encode_lds_bytes_per_block(p.lm);
+    const dim3 block(64u * encode_waves_per_block(p.lm));
     if (mode == MODE_ENCODE)
-        hipLaunchKernelGGL(encode_kernel<MODE_ENCODE>, dim3(blocks), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL(encode_kernel<MODE_ENCODE>, dim3(blocks), block, lds, stream, p);
     else
-        hipLaunchKernelGGL(encode_kernel<MODE_COUNT>, dim3(blocks), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL(encode_kernel<MODE_COUNT>, dim3(blocks), block, lds, stream, p);
     return hipGetLastError();
 }
 
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out) {
     const uint32_t lds = encode_lds_bytes_per_block(lm);
+    const int threads = (int)(64u * encode_waves_per_block(lm));
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
     hipError_t e;
     if (mode == MODE_ENCODE) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel<MODE_ENCODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode_kernel<MODE_ENCODE>, 256, lds);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode_kernel<MODE_ENCODE>, threads, lds);
     }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel<MODE_COUNT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode_kernel<MODE_COUNT>, 256, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode_kernel<MODE_COUNT>, threads, lds);
 }
 
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream) {

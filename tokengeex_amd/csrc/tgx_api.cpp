@@ -199,7 +199,8 @@ tgx_status ensure_scratch(tgx_corpus* c) {
 }
 
 uint32_t grid_blocks(const tgx_model* m, int mode, uint64_t n_samples) {
-    uint64_t want = (n_samples + 3) / 4;
+    const uint64_t wpb = tgx::encode_waves_per_block(m->lm);
+    uint64_t want = (n_samples + wpb - 1) / wpb;
     uint64_t cap = (uint64_t)m->num_cus * (uint64_t)std::max(1, m->blocks_per_cu[mode]);
     return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
 }
@@ -328,7 +329,7 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
     for (int mode = 0; mode < 2; mode++) {
         int occ = 0;
         HIP_TRY_M(tgx::encode_max_blocks_per_cu(m->lm, mode, &occ));
-        m->blocks_per_cu[mode] = std::max(1, std::min(occ, 8));
+        m->blocks_per_cu[mode] = std::max(1, std::min(occ, 16));
     }
     HIP_TRY_M(hipStreamSynchronize(m->stream));
 #undef HIP_TRY_M
