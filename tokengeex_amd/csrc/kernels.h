@@ -15,6 +15,7 @@ struct EncodeParams {
     const void* trie;               // TrieRec[n_slots] (16 B each)
     const uint32_t* tokid;          // u32[n_slots]
     uint32_t root_base;
+    uint32_t n_slots;               // trie slots (guards the handle -> id lookup)
     uint32_t lm;                    // max token length rounded up (<= 64)
     uint32_t* bp;                   // u32[N] back-pointer scratch
     uint32_t* tmp;                  // u32[N] right-aligned ids per sample (MODE_ENCODE)
@@ -24,6 +25,7 @@ struct EncodeParams {
     unsigned long long* err_sample; // min failing sample (init ~0)
     double dropout;
     uint64_t seed;
+    uint32_t flags;                 // timing experiments only (TGX_FLAGS env): see kernels.hip
 };
 
 struct CompactParams {

@@ -60,25 +60,292 @@ __device__ __forceinline__ double dropout_u01(uint64_t seed, uint64_t sample, ui
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// LDS bytes one wave needs for a given (rounded) max token length.
+// ---- LDS layout (per wave) ----------------------------------------------------
+// sc[row u = start position in the 64-block][col = len - 1] : f64 score
+// hl[same]                                                    : slot << 6 | (len - 1)
+// Row stride = LM entries; FRONT entries of padding in front and 64 behind, because
+// lanes that take no part in a relaxation step still issue their (ignored) read.
+constexpr uint32_t kFront = 2;
+__host__ __device__ inline uint32_t wave_lds_entries(uint32_t lm) { return 64u * lm + 64u + kFront; }
 __host__ __device__ inline uint32_t wave_lds_bytes(uint32_t lm) {
-    uint32_t entries = 64u * lm + 64u;  // +64: inactive lanes may read past a row
-    return entries * 8u + entries * 4u + 128u;
+    return wave_lds_entries(lm) * 12u + 128u;  // + 128 B text staging (generic path)
+}
+
+// D = mask[lane] ? t : f, with the 64-bit lane mask in an SGPR pair (no per-lane bit test)
+__device__ __forceinline__ uint32_t sel_u32(uint64_t mask, uint32_t t, uint32_t f) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ double sel_f64(uint64_t mask, double t, double f) {
+    const uint64_t tb = (uint64_t)__double_as_longlong(t), fb = (uint64_t)__double_as_longlong(f);
+    const uint32_t lo = sel_u32(mask, (uint32_t)tb, (uint32_t)fb);
+    const uint32_t hi = sel_u32(mask, (uint32_t)(tb >> 32), (uint32_t)(fb >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+struct WaveCtx {
+    const uint4* __restrict__ trie;
+    uint32_t root_base;
+    double dropout;
+    uint64_t seed;
+    bool use_dropout;
+    uint32_t flags;
+};
+
+// One 16-byte trie record in ONE load: the empty asm makes all four words live at
+// once (otherwise the compiler splits the load into three dependent round trips).
+__device__ __forceinline__ uint4 load_rec(const uint4* __restrict__ trie, uint32_t t) {
+    uint4 r = trie[t];
+    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w));
+    return r;
+}
+
+// ---- generic block: any LM <= 64, any number of positions (also the sample tail) ----
+// Processes positions p0 .. min(p0 + 63, n): match, relax, store the block's
+// back-pointers.  Sets reach_n when position n lies in this block.
+__device__ __forceinline__ void block_generic(const WaveCtx& C, const uint8_t* __restrict__ text, uint32_t n,
+                                              uint32_t s, uint32_t p0, uint32_t lane, uint32_t LM,
+                                              double* sc, uint32_t* hl, uint8_t* txt, uint32_t* __restrict__ bp,
+                                              double& acc, uint32_t& bpv, uint64_t& reach, uint32_t& reach_n) {
+    const uint32_t p = p0 + lane;
+    // stage the block's text (+ LM look-ahead) in LDS
+    txt[lane] = (p < n) ? text[p] : (uint8_t)0;
+    txt[lane + 64] = (p + 64 < n) ? text[p + 64] : (uint8_t)0;
+    __builtin_amdgcn_wave_barrier();
+
+    // match: TrieIterator::next (trie.rs:51-63) for 64 start positions at once
+    const uint32_t rem = (p < n) ? (n - p) : 0u;
+    const uint32_t maxd = rem < LM ? rem : LM;
+    uint32_t cur = 0, base = C.root_base;
+    uint64_t m = 0;
+    bool alive = maxd > 0;
+    if (C.flags & 1u) {  // experiment: no trie walk, fake 3 matches per position
+        alive = false;
+        m = maxd >= 3 ? 7ULL : (maxd ? 1ULL : 0ULL);
+    }
+    for (uint32_t d = 0; d < LM; ++d) {
+        alive = alive && (d < maxd);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+        if (alive) {
+            const uint32_t c = txt[lane + d];
+            const uint32_t t = base ^ c;
+            const uint4 r = load_rec(C.trie, t);
+            if (r.x == cur) {
+                cur = t;
+                base = r.y & 0x7FFFFFFFu;
+                if (r.y >> 31) {
+                    bool keep = true;
+                    // model.rs:100: kept iff dropout <= 0 || len <= 1 || dropout < rand
+                    if (C.use_dropout && d >= 1) keep = C.dropout < dropout_u01(C.seed, s, p, d + 1);
+                    if (keep) {
+                        m |= 1ULL << d;
+                        sc[kFront + lane * LM + d] = __hiloint2double((int)r.w, (int)r.z);
+                        hl[kFront + lane * LM + d] = (t << 6) | d;
+                    }
+                }
+            } else {
+                alive = false;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // relax: finalise positions p0 .. p0+63 in order (model.rs:83-110)
+    const uint32_t left = n - p0;  // positions < n in this block: min(64, left)
+    const uint32_t steps = left < 64u ? left : 64u;
+    uint32_t fin = 0;
+    for (uint32_t i = 0; i < ((C.flags & 2u) ? 0u : steps); ++i) {
+        fin = (lane == i) ? bpv : fin;  // back-pointer of position p0+i is final now
+        if (!((reach >> i) & 1ULL)) continue;  // model.rs:85-87 unreachable: skip
+        const double best = readlane_f64(acc, i);
+        const uint64_t mi = readlane_u64(m, i);
+        reach &= ~(1ULL << i);  // lane i now accumulates position p0 + i + 64
+        if (mi == 0) continue;
+        const uint64_t active = rotl64(mi, i + 1);  // length L -> lane (i + L) % 64
+        const uint32_t tj = (lane - i - 1u) & 63u;   // L - 1 for this lane
+        const double sv = sc[kFront + i * LM + tj];
+        const uint32_t hv = hl[kFront + i * LM + tj];
+        const double cand = best + sv;  // model.rs:98
+        const uint64_t gt = __builtin_amdgcn_ballot_w64(cand > acc);
+        const uint64_t take = active & (~reach | gt);  // model.rs:101: empty, or strict '>'
+        acc = sel_f64(take, cand, acc);
+        bpv = sel_u32(take, hv, bpv);
+        reach |= active;
+    }
+    if (left < 64u) {  // position n itself sits in this block
+        fin = (lane == left) ? bpv : fin;
+        reach_n = (uint32_t)((reach >> left) & 1ULL);
+    }
+    const uint32_t e = p0 + lane;
+    if (e >= 1 && e <= n) bp[e - 1] = fin;
+}
+
+// ---- fast block: LMT in {16, 32}, a FULL block (all 64 positions < n) --------------
+// Same arithmetic as block_generic with everything that can be static made static:
+// the text window lives in registers, the trie walk and the 64 relaxation steps are
+// fully unrolled (lane selects, rotate amounts and LDS offsets are immediates), masks
+// stay in SGPR pairs.  Back-pointers of lanes 0..31 are stored mid-block, 32..63 at
+// the end: with LMT <= 32 a lane is only overwritten (as accumulator of position
+// e + 64) after those points.
+template <int LMT>
+__device__ __forceinline__ void block_fast(const WaveCtx& C, const uint8_t* __restrict__ text, uint32_t n,
+                                           uint32_t s, uint32_t p0, uint32_t lane, double* sc, uint32_t* hl,
+                                           uint32_t* __restrict__ bp, double& acc, uint32_t& bpv,
+                                           uint64_t& reach) {
+    static_assert(LMT == 16 || LMT == 32, "fast path handles max token length <= 32");
+    const uint32_t p = p0 + lane;
+    // text window: bytes p .. p+LMT-1 from aligned dwords (the buffer is padded)
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(text + p);
+    const uint32_t sh = (uint32_t)(addr & 3u);
+    const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
+    uint32_t w[LMT / 4 + 1];
+#pragma unroll
+    for (int k = 0; k <= LMT / 4; ++k) w[k] = wp[k];
+    uint32_t bytes[LMT / 4];
+#pragma unroll
+    for (int k = 0; k < LMT / 4; ++k) bytes[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+
+    const uint32_t rem = n - p;  // > 0 in a full block
+    const uint32_t maxd = rem < (uint32_t)LMT ? rem : (uint32_t)LMT;
+    uint32_t cur = 0, base = C.root_base;
+    uint32_t m = 0;
+    bool alive = true;
+    if (C.flags & 1u) {
+        alive = false;
+        m = maxd >= 3 ? 7u : 1u;
+    }
+    double* scw = sc + kFront + lane * LMT;
+    uint32_t* hlw = hl + kFront + lane * LMT;
+#pragma unroll
+    for (int d = 0; d < LMT; ++d) {
+        alive = alive && ((uint32_t)d < maxd);
+        if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+        if (alive) {
+            const uint32_t c = (bytes[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+            const uint32_t t = base ^ c;
+            const uint4 r = load_rec(C.trie, t);
+            if (r.x == cur) {
+                cur = t;
+                base = r.y & 0x7FFFFFFFu;
+                if (r.y >> 31) {
+                    bool keep = true;
+                    if (C.use_dropout && d >= 1) keep = C.dropout < dropout_u01(C.seed, s, p, d + 1);
+                    if (keep) {
+                        m |= 1u << d;
+                        scw[d] = __hiloint2double((int)r.w, (int)r.z);
+                        hlw[d] = (t << 6) | (uint32_t)d;
+                    }
+                }
+            } else {
+                alive = false;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (C.flags & 2u) return;
+
+    // relax, 64 static steps.  Lane j reads row u at column (j - u - 1) & 63:
+    // entry index u*LMT + j - u - 1 (+64 for the lanes that wrapped, j <= u).
+    const double* scr = sc + kFront + lane - 1;  // + u*(LMT-1) [+64]
+    const uint32_t* hlr = hl + kFront + lane - 1;
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+        if (u == 32) {
+            if (lane < 32u && p >= 1u) bp[p - 1] = bpv;  // positions p0 .. p0+31 are final
+        }
+        const uint64_t ubit = 1ULL << u;
+        const bool reachable = (reach & ubit) != 0;  // model.rs:85-87
+        uint32_t mi = readlane_u32(m, (uint32_t)u);
+        mi = reachable ? mi : 0u;
+        const double best = readlane_f64(acc, (uint32_t)u);
+        reach &= ~ubit;  // lane u now accumulates position p0 + u + 64
+        const uint64_t active = rotl64((uint64_t)mi, (uint32_t)(u + 1));
+        double sv;
+        uint32_t hv;
+        if (u + LMT >= 64) {  // some targets wrap around the lane ring (u + L >= 64)
+            const uint64_t wrapped = (u == 63) ? ~0ULL : ((1ULL << (u + 1)) - 1ULL);  // lanes <= u
+            const uint32_t off = sel_u32(wrapped, 64u, 0u);
+            sv = scr[u * (LMT - 1) + (int)off];
+            hv = hlr[u * (LMT - 1) + (int)off];
+        } else {
+            sv = scr[u * (LMT - 1)];
+            hv = hlr[u * (LMT - 1)];
+        }
+        const double cand = best + sv;  // model.rs:98
+        const uint64_t gt = __builtin_amdgcn_ballot_w64(cand > acc);
+        const uint64_t take = active & (~reach | gt);  // model.rs:101
+        acc = sel_f64(take, cand, acc);
+        bpv = sel_u32(take, hv, bpv);
+        reach |= active;
+    }
+    if (lane >= 32u) bp[p - 1] = bpv;  // positions p0+32 .. p0+63
 }
 
 template <int MODE>
+__device__ __forceinline__ void trace_sample(const EncodeParams& P, uint32_t s, uint64_t beg, uint32_t n,
+                                             uint32_t lane, const uint32_t* __restrict__ bp, uint32_t reach_n) {
+    // follow the back-pointers from n (model.rs:113-126), 64 positions per hop group
+    __threadfence_block();  // this wave's bp stores are read back below
+    uint32_t total = 0;
+    uint64_t cursor = beg + n;  // one past this sample's slice of tmp
+    // Error::NoPath(n, n), model.rs:119: nothing to trace, the sample is reported below
+    int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // index into bp of the current end position
+    if (P.flags & 4u) q = -1;  // experiment: no trace
+    while (q >= 0) {
+        const uint32_t wq = (uint32_t)q & ~63u;
+        const uint32_t idx = wq + lane;
+        const uint32_t h = (idx < n) ? bp[idx] : 0u;
+        uint64_t ends = 0;
+        int32_t qq = (int32_t)((uint32_t)q - wq);
+        while (qq >= 0) {
+            const uint32_t hh = readlane_u32(h, (uint32_t)qq);
+            ends |= 1ULL << qq;
+            qq -= (int32_t)(hh & 63u) + 1;
+        }
+        q = (int64_t)wq + qq;
+        const uint32_t cnt = (uint32_t)__popcll(ends);
+        if ((ends >> lane) & 1ULL) {
+            // a handle outside the table can only come from a kernel bug; report it as a
+            // failed sample instead of faulting the device
+            const uint32_t slot = h >> 6;
+            if (slot >= P.n_slots) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
+            const uint32_t id = slot < P.n_slots ? P.tokid[slot] : 0u;
+            if (MODE == MODE_ENCODE) {
+                const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
+                P.tmp[cursor - 1 - above] = id;
+            } else {
+                atomicAdd(&P.freq[id], 1ULL);
+            }
+        }
+        cursor -= cnt;
+        total += cnt;
+    }
+    if (lane == 0) {
+        P.counts[s] = total;
+        if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);
+    }
+}
+
+// LMT = 0: generic (runtime LM <= 64); LMT = 16 / 32: fast path for full blocks.
+template <int MODE, int LMT>
 __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t LM = P.lm;
-    const uint32_t entries = 64u * LM + 64u;
+    const uint32_t LM = LMT ? (uint32_t)LMT : P.lm;
+    const uint32_t entries = wave_lds_entries(LM);
     unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(LM);
     double* sc = reinterpret_cast<double*>(wbase);
     uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + (size_t)entries * 8u);
     uint8_t* txt = reinterpret_cast<uint8_t*>(wbase + (size_t)entries * 12u);
-    const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
-    const bool use_dropout = P.dropout > 0.0;
+    WaveCtx C;
+    C.trie = reinterpret_cast<const uint4*>(P.trie);
+    C.root_base = P.root_base;
+    C.dropout = P.dropout;
+    C.seed = P.seed;
+    C.use_dropout = P.dropout > 0.0;
+    C.flags = P.flags;
 
     // Static round-robin over the longest-first order: wave w takes samples w, w + W,
     // w + 2W, ...  (no work queue: every wave's trip count is known at launch).
@@ -97,113 +364,15 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
         uint64_t reach = 1;  // wave-uniform: bit j = lane j holds a value (position 0: score 0)
         uint32_t reach_n = (n == 0) ? 1u : 0u;
 
-        for (uint32_t p0 = 0; p0 <= n; p0 += 64) {
-            const uint32_t p = p0 + lane;
-            // ---- stage the block's text (+ LM look-ahead) in LDS
-            txt[lane] = (p < n) ? text[p] : (uint8_t)0;
-            txt[lane + 64] = (p + 64 < n) ? text[p + 64] : (uint8_t)0;
-            __builtin_amdgcn_wave_barrier();
-
-            // ---- match: TrieIterator::next (trie.rs:51-63) for 64 start positions at once
-            const uint32_t rem = (p < n) ? (n - p) : 0u;
-            const uint32_t maxd = rem < LM ? rem : LM;
-            uint32_t cur = 0, base = P.root_base;
-            uint64_t m = 0;
-            bool alive = maxd > 0;
-            for (uint32_t d = 0; d < LM; ++d) {
-                alive = alive && (d < maxd);
-                if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
-                if (alive) {
-                    const uint32_t c = txt[lane + d];
-                    const uint32_t t = base ^ c;
-                    const uint4 r = trie[t];
-                    if (r.x == cur) {
-                        cur = t;
-                        base = r.y & 0x7FFFFFFFu;
-                        if (r.y >> 31) {
-                            bool keep = true;
-                            // model.rs:100: kept iff dropout <= 0 || len <= 1 || dropout < rand
-                            if (use_dropout && d >= 1)
-                                keep = P.dropout < dropout_u01(P.seed, s, p, d + 1);
-                            if (keep) {
-                                m |= 1ULL << d;
-                                sc[lane * LM + d] = __hiloint2double((int)r.w, (int)r.z);
-                                hl[lane * LM + d] = (t << 6) | d;
-                            }
-                        }
-                    } else {
-                        alive = false;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-
-            // ---- relax: finalise positions p0 .. p0+63 in order (model.rs:83-110)
-            const uint32_t left = n - p0;  // positions < n in this block: min(64, left)
-            const uint32_t steps = left < 64u ? left : 64u;
-            uint32_t fin = 0;
-            for (uint32_t i = 0; i < steps; ++i) {
-                fin = (lane == i) ? bpv : fin;  // back-pointer of position p0+i is final now
-                if (!((reach >> i) & 1ULL)) continue;  // model.rs:85-87 unreachable: skip
-                const double best = readlane_f64(acc, i);
-                const uint64_t mi = readlane_u64(m, i);
-                reach &= ~(1ULL << i);  // lane i now accumulates position p0 + i + 64
-                if (mi == 0) continue;
-                const uint64_t active = rotl64(mi, i + 1);  // length L -> lane (i + L) % 64
-                const uint32_t tj = (lane - i - 1u) & 63u;   // L - 1 for this lane
-                const double sv = sc[i * LM + tj];
-                const uint32_t hv = hl[i * LM + tj];
-                const double cand = best + sv;  // model.rs:98
-                const bool act = (active >> lane) & 1ULL;
-                const bool had = (reach >> lane) & 1ULL;
-                const bool take = act && (!had || cand > acc);  // model.rs:101 strict '>'
-                acc = take ? cand : acc;
-                bpv = take ? hv : bpv;
-                reach |= active;
-            }
-            if (left < 64u) {  // position n itself sits in this block
-                fin = (lane == left) ? bpv : fin;
-                reach_n = (uint32_t)((reach >> left) & 1ULL);
-            }
-            const uint32_t e = p0 + lane;
-            if (e >= 1 && e <= n) bp[e - 1] = fin;
+        uint32_t p0 = 0;
+        if (LMT != 0) {
+            for (; p0 + 64u <= n; p0 += 64u)
+                block_fast<(LMT ? LMT : 16)>(C, text, n, s, p0, lane, sc, hl, bp, acc, bpv, reach);
         }
+        for (; p0 <= n; p0 += 64u)
+            block_generic(C, text, n, s, p0, lane, LM, sc, hl, txt, bp, acc, bpv, reach, reach_n);
 
-        // ---- trace: follow the back-pointers from n (model.rs:113-126), 64 positions per hop group
-        __threadfence_block();  // this wave's bp stores above are read back below
-        uint32_t total = 0;
-        uint64_t cursor = beg + n;  // one past this sample's slice of tmp
-        // Error::NoPath(n, n), model.rs:119: nothing to trace, the sample is reported below
-        int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // index into bp of the current end position
-        while (q >= 0) {
-            const uint32_t wq = (uint32_t)q & ~63u;
-            const uint32_t idx = wq + lane;
-            const uint32_t h = (idx < n) ? bp[idx] : 0u;
-            uint64_t ends = 0;
-            int32_t qq = (int32_t)((uint32_t)q - wq);
-            while (qq >= 0) {
-                const uint32_t hh = readlane_u32(h, (uint32_t)qq);
-                ends |= 1ULL << qq;
-                qq -= (int32_t)(hh & 63u) + 1;
-            }
-            q = (int64_t)wq + qq;
-            const uint32_t cnt = (uint32_t)__popcll(ends);
-            if ((ends >> lane) & 1ULL) {
-                const uint32_t id = P.tokid[h >> 6];
-                if (MODE == MODE_ENCODE) {
-                    const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
-                    P.tmp[cursor - 1 - above] = id;
-                } else {
-                    atomicAdd(&P.freq[id], 1ULL);
-                }
-            }
-            cursor -= cnt;
-            total += cnt;
-        }
-        if (lane == 0) {
-            P.counts[s] = total;
-            if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);
-        }
+        trace_sample<MODE>(P, s, beg, n, lane, bp, reach_n);
     }
 }
 
@@ -255,20 +424,39 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams P) {
 
 // ---- launchers -------------------------------------------------------------
 
+// kernel specialisation for a (rounded) max token length: fast paths need LM == LMT
+static int lmt_for(uint32_t lm) { return lm <= 16u ? 16 : (lm <= 32u ? 32 : 0); }
+uint32_t encode_effective_lm(uint32_t lm) {
+    const int t = lmt_for(lm);
+    return t ? (uint32_t)t : lm;
+}
+
 // Waves per block: as many (<= 4) as keep one block's LDS within 64 KiB.
 uint32_t encode_waves_per_block(uint32_t lm) {
-    uint32_t w = (64u * 1024u) / wave_lds_bytes(lm);
+    uint32_t w = (64u * 1024u) / wave_lds_bytes(encode_effective_lm(lm));
     return w < 1u ? 1u : (w > 4u ? 4u : w);
 }
-uint32_t encode_lds_bytes_per_block(uint32_t lm) { return encode_waves_per_block(lm) * wave_lds_bytes(lm); }
+uint32_t encode_lds_bytes_per_block(uint32_t lm) {
+    return encode_waves_per_block(lm) * wave_lds_bytes(encode_effective_lm(lm));
+}
+
+typedef void (*encode_fn)(EncodeParams);
+static encode_fn pick_kernel(int mode, uint32_t lm) {
+    const int t = lmt_for(lm);
+    if (mode == MODE_ENCODE) {
+        if (t == 16) return encode_kernel<MODE_ENCODE, 16>;
+        if (t == 32) return encode_kernel<MODE_ENCODE, 32>;
+        return encode_kernel<MODE_ENCODE, 0>;
+    }
+    if (t == 16) return encode_kernel<MODE_COUNT, 16>;
+    if (t == 32) return encode_kernel<MODE_COUNT, 32>;
+    return encode_kernel<MODE_COUNT, 0>;
+}
 
 hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream) {
     const uint32_t lds = encode_lds_bytes_per_block(p.lm);
     const dim3 block(64u * encode_waves_per_block(p.lm));
-    if (mode == MODE_ENCODE)
-        hipLaunchKernelGGL(encode_kernel<MODE_ENCODE>, dim3(blocks), block, lds, stream, p);
-    else
-        hipLaunchKernelGGL(encode_kernel<MODE_COUNT>, dim3(blocks), block, lds, stream, p);
+    hipLaunchKernelGGL(pick_kernel(mode, p.lm), dim3(blocks), block, lds, stream, p);
     return hipGetLastError();
 }
 
@@ -276,17 +464,11 @@ hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out) {
     const uint32_t lds = encode_lds_bytes_per_block(lm);
     const int threads = (int)(64u * encode_waves_per_block(lm));
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
-    hipError_t e;
-    if (mode == MODE_ENCODE) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel<MODE_ENCODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode_kernel<MODE_ENCODE>, threads, lds);
-    }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(encode_kernel<MODE_COUNT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    encode_fn fn = pick_kernel(mode, lm);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode_kernel<MODE_COUNT>, threads, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, threads, lds);
 }
 
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream) {

@@ -222,6 +222,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     p.tokid = m->d_tokid;
     p.root_base = m->flat.table[0].base & ~tgx::kTerminalBit;
     p.lm = m->lm;
+    p.n_slots = (uint32_t)m->flat.table.size();
     p.bp = c->d_bp;
     p.tmp = c->d_tmp;
     p.counts = c->d_counts;
@@ -230,6 +231,10 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     p.err_sample = m->d_ctrl + 1;
     p.dropout = dropout;
     p.seed = seed;
+    {
+        const char* f = getenv("TGX_FLAGS");  // timing experiments only; results are wrong when set
+        p.flags = f ? (uint32_t)atoi(f) : 0u;
+    }
     if (debug_on())
         fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u blocks=%u lds=%u slots=%zu root_base=%u\n",
                 (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm,
@@ -244,6 +249,9 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
 tgx_status check_no_path(tgx_model* m, const tgx_corpus* c) {
     unsigned long long bad = m->h_ctrl[0];
     if (bad == ~0ULL) return TGX_OK;
+    if (bad & (1ULL << 62))
+        return fail(TGX_ERR_DEVICE, "internal error: corrupt back-pointer in sample %llu",
+                    (unsigned long long)(bad & ~(1ULL << 62)));
     uint64_t n = c->h_offs[bad + 1] - c->h_offs[bad];
     g_err_sample = bad;
     g_err_pos = n;
