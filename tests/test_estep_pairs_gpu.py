@@ -1,0 +1,135 @@
+"""GPU parity for the prune / merge corpus passes: E-step expected counts
+(tolerance: the backward fold order and exp/log differ from the reference, see
+estep.hip), and the pair scan (bit-exact)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import tokengeex_amd as tgx
+from oracle import oracle as orc
+from tokengeex_amd import synth
+
+from util import corpus_and_vocab
+
+# Parity criterion for expected[] (1e-9 relative, 1e-12 absolute floor) holds for
+# snippets up to a few KiB.  For longer snippets the quantity exp(A + s + B - z) is a difference of
+# log-probabilities of magnitude |z| ~ 2.4 * bytes (ulp(2e5) = 2.9e-11 at 81920 bytes) whose rounding
+# errors random-walk along the recursion, so two correct f64 evaluations that differ in fold order or
+# in the last bit of exp/log differ by ~sqrt(n) * ulp(|z|) in the exponent: ~1e-8 relative at the
+# reference's 81920-byte snippets.  The tolerance therefore scales with the snippet length.
+ATOL = 1e-12
+
+
+def rtol_for(snippet_bytes):
+    return 1e-9 * max(1.0, snippet_bytes / 4096.0)
+
+
+def _pair(tokens, scores):
+    return tgx.NativeModel(tokens, scores), orc.OracleModel(tokens, scores)
+
+
+def _check_estep(nat, ora, flat, offs, snippet_len=81920, dropout=0.0, seed=0, rtol=None):
+    if rtol is None:
+        longest = int(np.diff(offs.astype(np.int64)).max()) if offs.size > 1 else 0
+        rtol = rtol_for(min(snippet_len, longest))
+    corpus = tgx.NativeCorpus(flat, offs)
+    got, gz = nat.estep(corpus, snippet_len, dropout, seed)
+    st, want, wz, _ = ora.estep_flat(flat, offs, snippet_len, dropout, seed, threads=8)
+    assert st == orc.OK
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=ATOL)
+    assert np.array_equal(got != 0, want != 0)  # same set of ids with mass
+    assert abs(gz - wz) <= 1e-12 * abs(wz) + 1e-9
+    return got, gz
+
+
+def test_marginal_kat_on_gpu(golden_dir):
+    with open(os.path.join(golden_dir, "reference_kats.json"), encoding="utf-8") as f:
+        k = json.load(f)["marginal"]
+    toks = [t.encode() for t, _ in k["vocab"]]
+    nat = tgx.NativeModel(toks, [s for _, s in k["vocab"]])
+    flat, offs = tgx.pack([k["input"].encode()])
+    exp, z = nat.estep(tgx.NativeCorpus(flat, offs))
+    names = [t for t, _ in k["vocab"]]
+    for name, want in k["expected"].items():
+        assert abs(exp[names.index(name)] - want) < 5e-7, name
+    assert abs(z - (-12.0 + math.log(1.0 + math.exp(-1.0) + math.exp(-2.0)))) < 1e-12
+
+
+def test_estep_small_cases_and_quirks():
+    # no single-byte cover: positions without incoming / outgoing tokens keep 0.0 (lattice.rs:255-256)
+    toks = [b"a", b"b", b"ab", b"ba", b"aba", b"c", b"bcb"]
+    scores = [-1.0, -1.5, -1.7, -2.0, -2.2, -3.0, -0.5]
+    nat, ora = _pair(toks, scores)
+    texts = [b"abaabab", b"a", b"abcba", b"cbcb", b"ab" * 100, b"aba" * 43 + b"c", b"bcbcb"]
+    flat, offs = tgx.pack(texts)
+    _check_estep(nat, ora, flat, offs)
+    _check_estep(nat, ora, flat, offs, snippet_len=3)    # "aba","aba","b": cuts through tokens (prune.rs:83)
+    _check_estep(nat, ora, flat, offs, snippet_len=64)   # exactly one block
+    _check_estep(nat, ora, flat, offs, snippet_len=65)
+
+
+def test_estep_realistic_corpus():
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 8000, 16)
+    nat, ora = _pair(toks, scores)
+    got, _ = _check_estep(nat, ora, flat, offs)
+    # every byte of the corpus is covered with total mass 1
+    mass = float(sum(got[i] * len(toks[i]) for i in range(len(toks))))
+    assert abs(mass - flat.size) < 1e-6 * flat.size
+    assert "estep_kernel" in nat.last_kernel_times()
+
+
+def test_estep_snippets_long_samples_and_token_lengths():
+    flat, offs = synth.make_corpus(1 << 20, "mixed", seed_offset=5)
+    rng = np.random.default_rng(9)
+    for max_len in (5, 24, 40):
+        toks, scores = synth.random_vocab(rng, bytes(flat[: 64 << 10]), 2500, max_len, tie_fraction=0.0)
+        nat, ora = _pair(toks, scores)
+        offs2 = np.array([0, 300000, 300001, flat.size], dtype=np.uint64)  # long samples -> several snippets
+        _check_estep(nat, ora, flat, offs2, snippet_len=81920)
+        _check_estep(nat, ora, flat[: 200000], np.array([0, 200000], dtype=np.uint64), snippet_len=1000)
+
+
+def test_estep_dropout_matches_oracle_decisions():
+    flat, offs, toks, scores = corpus_and_vocab(512 << 10, "mixed", 3000, 12)
+    nat, ora = _pair(toks, scores)
+    _check_estep(nat, ora, flat, offs, dropout=0.1, seed=42)
+    _check_estep(nat, ora, flat, offs, snippet_len=5000, dropout=0.5, seed=7)
+
+
+def test_estep_z_not_normal_is_reported():
+    nat, ora = _pair([b"a", b"b"], [0.0, -1.0])
+    flat, offs = tgx.pack([b"bb", b"aa", b"ab"])  # z("aa") == 0.0 -> not normal (prune.rs:90-96)
+    corpus = tgx.NativeCorpus(flat, offs)
+    with pytest.raises(tgx.TokenGeeXError) as e:
+        nat.estep(corpus)
+    assert e.value.status == 6 and e.value.sample == 1
+    st, _, _, es = ora.estep_flat(flat, offs)
+    assert st == orc.ERR_Z_NOT_NORMAL and es == 1
+
+
+def test_count_pairs_parity():
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 6000, 16)
+    nat, ora = _pair(toks, scores)
+    corpus = tgx.NativeCorpus(flat, offs)
+    keys, counts = nat.count_pairs(corpus)
+    wk, wc = ora.count_pairs_flat(flat, offs, threads=8)
+    np.testing.assert_array_equal(keys, wk)
+    np.testing.assert_array_equal(counts, wc)
+    assert "pair_keys_kernel" in nat.last_kernel_times()
+
+
+def test_count_pairs_small_and_empty():
+    nat, ora = _pair([b"a", b"b", b"c", b"ab"], [-3.0, -3.0, -3.0, -4.0])
+    texts = [b"abc", b"abab", b"c", b"", b"ababab"]
+    flat, offs = tgx.pack(texts)
+    keys, counts = nat.count_pairs(tgx.NativeCorpus(flat, offs))
+    got = {(int(k) >> 32, int(k) & 0xFFFFFFFF): int(c) for k, c in zip(keys, counts)}
+    assert got == {(3, 2): 1, (3, 3): 3}
+    flat, offs = tgx.pack([b"", b"c"])
+    keys, counts = nat.count_pairs(tgx.NativeCorpus(flat, offs))
+    assert keys.size == 0 and counts.size == 0

@@ -15,8 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtgx.so")
-SOURCES = ["kernels.hip", "tgx_api.cpp", "trie_build.cpp"]
-HEADERS = ["kernels.h", "trie_build.h", os.path.join("..", "..", "include", "tgx.h")]
+SOURCES = ["kernels.hip", "estep.hip", "pairs.hip", "tgx_api.cpp", "trie_build.cpp"]
+HEADERS = ["kernels.h", "device_common.h", "trie_build.h", os.path.join("..", "..", "include", "tgx.h")]
 ARCH = "gfx950"
 
 
@@ -54,6 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return OUT
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off",  # the DP's f64 adds must not be fused or reassociated
+           "-munsafe-fp-atomics",  # f64 atomicAdd as one hardware atomic (E-step counts)
            "-Wall", "-Wno-unused-result",
            "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + [
            "-o", OUT + ".tmp", "-Wl,-rpath,/opt/rocm/lib"]

@@ -38,6 +38,39 @@ struct CompactParams {
     unsigned long long* next;
 };
 
+struct EstepParams {
+    const uint8_t* text;
+    const uint64_t* offs;
+    const uint32_t* order;
+    uint64_t n_samples;
+    const void* trie_fwd;           // tokens as written (forward sweep)
+    const void* trie_rev;           // reversed tokens (backward sweep)
+    uint32_t root_fwd, root_rev;
+    uint32_t lm;                    // max token length rounded up (<= 64)
+    uint64_t snippet_len;           // 81920 in the reference (prune.rs:75)
+    double* alpha;                  // f64[N + S + pad] forward values, sample s at offs[s] + s
+    double* expected_slot;          // f64[n_slots_rev] expected counts per reversed-trie slot
+    double* logz_sum;
+    unsigned long long* err_sample; // min sample whose z is not normal (init ~0)
+    double dropout;
+    uint64_t seed;
+};
+
+hipError_t launch_pair_keys(const uint32_t* ids, const uint64_t* out_offs, uint64_t n_samples,
+                            unsigned long long* keys, uint32_t blocks, hipStream_t stream);
+hipError_t pair_sort_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t pair_sort(void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out,
+                     uint64_t n, hipStream_t stream);
+hipError_t pair_rle_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t pair_rle(void* temp, size_t temp_bytes, const unsigned long long* sorted, uint64_t n,
+                    unsigned long long* unique_out, unsigned int* counts_out, unsigned int* n_runs_out,
+                    hipStream_t stream);
+
+uint32_t estep_lds_bytes_per_block(uint32_t lm);
+uint32_t estep_waves_per_block(uint32_t lm);
+hipError_t estep_max_blocks_per_cu(uint32_t lm, int* out);
+hipError_t launch_estep(const EstepParams& p, uint32_t blocks, hipStream_t stream);
+
 uint32_t encode_lds_bytes_per_block(uint32_t lm);
 uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out);

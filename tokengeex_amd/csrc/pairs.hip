@@ -1,0 +1,71 @@
+// Pair scan of `merge`: adjacent token-id pairs inside each sample.
+//
+// Replaces the per-chunk FnvHashMap<(u32,u32),usize> + RwLock merge of the reference
+// (src/merge.rs:53-76) with a deterministic device pipeline over the ids produced by
+// the encode kernel: one u64 key (a << 32 | b) per token slot (the last token of a
+// sample gets a sentinel), radix sort (rocPRIM), run-length encode.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+
+#include "kernels.h"
+
+namespace tgx {
+
+constexpr unsigned long long kPairSentinel = ~0ULL;  // ids are < 2^32 - 1, never a real pair
+
+// keys[o + i] = (ids[o+i] << 32) | ids[o+i+1] for i < cnt - 1 (merge.rs:60-63), sentinel for i = cnt - 1
+__global__ __launch_bounds__(256) void pair_keys_kernel(const uint32_t* __restrict__ ids,
+                                                        const uint64_t* __restrict__ out_offs,
+                                                        uint64_t n_samples,
+                                                        unsigned long long* __restrict__ keys) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t wave_id = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (uint64_t s = wave_id; s < n_samples; s += n_waves) {
+        const uint64_t o = out_offs[s];
+        const uint64_t cnt = out_offs[s + 1] - o;
+        for (uint64_t i = lane; i < cnt; i += 64) {
+            const unsigned long long a = ids[o + i];
+            keys[o + i] = (i + 1 < cnt) ? ((a << 32) | (unsigned long long)ids[o + i + 1]) : kPairSentinel;
+        }
+    }
+}
+
+hipError_t launch_pair_keys(const uint32_t* ids, const uint64_t* out_offs, uint64_t n_samples,
+                            unsigned long long* keys, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(pair_keys_kernel, dim3(blocks), dim3(256), 0, stream, ids, out_offs, n_samples, keys);
+    return hipGetLastError();
+}
+
+hipError_t pair_sort_temp_bytes(uint64_t n, size_t* bytes) {
+    unsigned long long* p = nullptr;
+    size_t b = 0;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, b, p, p, (size_t)n);
+    *bytes = b;
+    return e;
+}
+hipError_t pair_sort(void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out,
+                     uint64_t n, hipStream_t stream) {
+    return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, 64, stream);
+}
+hipError_t pair_rle_temp_bytes(uint64_t n, size_t* bytes) {
+    unsigned long long* p = nullptr;
+    unsigned int* c = nullptr;
+    size_t b = 0;
+    hipError_t e = rocprim::run_length_encode(nullptr, b, p, (unsigned int)n, p, c, c);
+    *bytes = b;
+    return e;
+}
+hipError_t pair_rle(void* temp, size_t temp_bytes, const unsigned long long* sorted, uint64_t n,
+                    unsigned long long* unique_out, unsigned int* counts_out, unsigned int* n_runs_out,
+                    hipStream_t stream) {
+    return rocprim::run_length_encode(temp, temp_bytes, sorted, (unsigned int)n, unique_out, counts_out,
+                                      n_runs_out, stream);
+}
+
+}  // namespace tgx

@@ -117,6 +117,13 @@ struct tgx_model {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     int blocks_per_cu[2] = {0, 0};
+    // E-step only (built on first use): trie of the reversed tokens
+    std::vector<uint8_t> vocab_bytes;
+    std::vector<uint64_t> vocab_offs;
+    std::vector<double> vocab_scores;
+    tgx::FlatTrie flat_rev;
+    void* d_trie_rev = nullptr;
+    int estep_blocks_per_cu = 0;
     KernelTime timed[kMaxTimed] = {};
     int n_timed = 0;
     uint64_t last_alg_bytes = 0;
@@ -303,6 +310,14 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
         return fail(TGX_ERR_UNSUPPORTED, "trie needs more than 2^26 slots");
     }
     m->lm = std::max<uint32_t>(4, (m->flat.max_token_len + 3) & ~3u);
+    if (vocab_size) {
+        m->vocab_bytes.assign(bytes + offs[0], bytes + offs[vocab_size]);
+        m->vocab_offs.resize(vocab_size + 1);
+        for (uint32_t i = 0; i <= vocab_size; i++) m->vocab_offs[i] = offs[i] - offs[0];
+        m->vocab_scores.assign(scores, scores + vocab_size);
+    } else {
+        m->vocab_offs.assign(1, 0);
+    }
 
     auto cleanup = [&](tgx_status st) {
         tgx_model_destroy(m);
@@ -354,6 +369,7 @@ void tgx_model_destroy(tgx_model* m) {
         if (m->timed[i].stop) (void)hipEventDestroy(m->timed[i].stop);
     }
     if (m->d_trie) (void)hipFree(m->d_trie);
+    if (m->d_trie_rev) (void)hipFree(m->d_trie_rev);
     if (m->d_tokid) (void)hipFree(m->d_tokid);
     if (m->d_ctrl) (void)hipFree(m->d_ctrl);
     if (m->h_ctrl) (void)hipHostFree(m->h_ctrl);
@@ -483,12 +499,9 @@ uint64_t tgx_corpus_num_bytes(const tgx_corpus* c) { return c ? c->n_bytes : 0; 
 
 // ---- encode --------------------------------------------------------------------
 
-tgx_status tgx_encode_corpus(tgx_model* m, tgx_corpus* c, double dropout, uint64_t seed,
-                             tgx_result** out) {
-    if (!m || !c || !out) return fail(TGX_ERR_INVALID, "tgx_encode_corpus: NULL argument");
-    *out = nullptr;
-    if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
-    std::lock_guard<std::mutex> lk(m->mu);
+// caller holds m->mu
+static tgx_status encode_corpus_locked(tgx_model* m, tgx_corpus* c, double dropout, uint64_t seed,
+                                       tgx_result** out) {
     HIP_TRY(hipSetDevice(m->device));
     m->n_timed = 0;
     const uint64_t S = c->n_samples;
@@ -540,6 +553,15 @@ tgx_status tgx_encode_corpus(tgx_model* m, tgx_corpus* c, double dropout, uint64
     m->last_alg_bytes = c->n_bytes + 4 * r->n_tokens + 16 * (S + 1);
     *out = r;
     return TGX_OK;
+}
+
+tgx_status tgx_encode_corpus(tgx_model* m, tgx_corpus* c, double dropout, uint64_t seed,
+                             tgx_result** out) {
+    if (!m || !c || !out) return fail(TGX_ERR_INVALID, "tgx_encode_corpus: NULL argument");
+    *out = nullptr;
+    if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
+    std::lock_guard<std::mutex> lk(m->mu);
+    return encode_corpus_locked(m, c, dropout, seed, out);
 }
 
 tgx_status tgx_encode_batch(tgx_model* m, const uint8_t* text, const uint64_t* offs,
@@ -630,14 +652,175 @@ tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
 
 tgx_status tgx_count_pairs(tgx_model* m, tgx_corpus* c, uint64_t** keys, uint64_t** counts,
                            uint64_t* n_pairs) {
-    (void)m; (void)c; (void)keys; (void)counts; (void)n_pairs;
-    return fail(TGX_ERR_UNSUPPORTED, "tgx_count_pairs: not implemented yet");
+    if (!m || !c || !keys || !counts || !n_pairs) return fail(TGX_ERR_INVALID, "tgx_count_pairs: NULL argument");
+    *keys = *counts = nullptr;
+    *n_pairs = 0;
+    if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
+    std::lock_guard<std::mutex> lk(m->mu);
+    tgx_result* r = nullptr;
+    tgx_status st = encode_corpus_locked(m, c, 0.0, 0, &r);  // model.encode(sample, 0.0), merge.rs:58
+    if (st != TGX_OK) return st;
+    const uint64_t T = r->n_tokens, S = r->n_samples;
+    if (T >= 0xFFFFFFFFull) {
+        tgx_result_free(r);
+        return fail(TGX_ERR_UNSUPPORTED, "pair scan over more than 2^32-1 tokens per pass");
+    }
+    unsigned long long *d_keys = nullptr, *d_sorted = nullptr, *d_unique = nullptr;
+    unsigned int *d_cnt = nullptr, *d_runs = nullptr;
+    void* d_temp = nullptr;
+    size_t tb1 = 0, tb2 = 0;
+    const size_t kb = (size_t)T * 8 + 256, cb = (size_t)T * 4 + 256;
+    auto cleanup = [&](tgx_status s2) {
+        pool_free(m->device, d_keys, kb);
+        pool_free(m->device, d_sorted, kb);
+        pool_free(m->device, d_unique, kb);
+        pool_free(m->device, d_cnt, cb);
+        pool_free(m->device, d_runs, 256);
+        pool_free(m->device, d_temp, std::max(tb1, tb2) + 256);
+        tgx_result_free(r);
+        return s2;
+    };
+    if (T == 0) return cleanup(TGX_OK);
+    if (tgx::pair_sort_temp_bytes(T, &tb1) != hipSuccess || tgx::pair_rle_temp_bytes(T, &tb2) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "rocPRIM temp-size query failed"));
+    if (pool_alloc(m->device, kb, (void**)&d_keys) != hipSuccess ||
+        pool_alloc(m->device, kb, (void**)&d_sorted) != hipSuccess ||
+        pool_alloc(m->device, kb, (void**)&d_unique) != hipSuccess ||
+        pool_alloc(m->device, cb, (void**)&d_cnt) != hipSuccess ||
+        pool_alloc(m->device, 256, (void**)&d_runs) != hipSuccess ||
+        pool_alloc(m->device, std::max(tb1, tb2) + 256, &d_temp) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (pair scan)"));
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((S + 3) / 4, (uint64_t)m->num_cus * 8));
+    time_begin(m, "pair_keys_kernel");
+    if (tgx::launch_pair_keys(r->d_ids, r->d_offs, S, d_keys, blocks, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "pair key launch failed"));
+    time_end(m);
+    time_begin(m, "pair_sort+rle");
+    if (tgx::pair_sort(d_temp, tb1, d_keys, d_sorted, T, m->stream) != hipSuccess ||
+        tgx::pair_rle(d_temp, tb2, d_sorted, T, d_unique, d_cnt, d_runs, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "pair sort / run-length encode failed"));
+    time_end(m);
+    unsigned int runs = 0;
+    if (hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "pair scan failed: %s", hipGetErrorString(hipGetLastError())));
+    std::vector<unsigned long long> hk(runs ? runs : 1);
+    std::vector<unsigned int> hc(runs ? runs : 1);
+    if (runs && (hipMemcpy(hk.data(), d_unique, (size_t)runs * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                 hipMemcpy(hc.data(), d_cnt, (size_t)runs * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        return cleanup(fail(TGX_ERR_DEVICE, "D2H copy of pair table failed"));
+    if (runs && hk[runs - 1] == ~0ULL) runs--;  // the sentinel run (one per non-empty sample) sorts last
+    uint64_t* ok = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
+    uint64_t* oc = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
+    for (unsigned int i = 0; i < runs; i++) {
+        ok[i] = hk[i];
+        oc[i] = hc[i];
+    }
+    *keys = ok;
+    *counts = oc;
+    *n_pairs = runs;
+    // N + 8(S+1) + 16P
+    m->last_alg_bytes = c->n_bytes + 8 * (S + 1) + 16ull * runs;
+    return cleanup(TGX_OK);
+}
+
+// Builds (once) the double-array of the REVERSED tokens used by the backward sweep.
+static tgx_status ensure_reverse_trie(tgx_model* m) {
+    if (m->d_trie_rev) return TGX_OK;
+    const uint32_t V = m->vocab_size;
+    std::vector<uint8_t> rev(m->vocab_bytes.size());
+    for (uint32_t i = 0; i < V; i++) {
+        const uint64_t b = m->vocab_offs[i], e = m->vocab_offs[i + 1];
+        for (uint64_t k = b; k < e; k++) rev[k] = m->vocab_bytes[e - 1 - (k - b)];
+    }
+    tgx::build_flat_trie(rev.data(), m->vocab_offs.data(), m->vocab_scores.data(), V, &m->flat_rev);
+    if (m->flat_rev.table.size() >= (1u << 26)) return fail(TGX_ERR_UNSUPPORTED, "reversed trie needs more than 2^26 slots");
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t tbytes = m->flat_rev.table.size() * sizeof(tgx::TrieRec);
+    HIP_TRY(hipMalloc(&m->d_trie_rev, tbytes));
+    HIP_TRY(hipMemcpy(m->d_trie_rev, m->flat_rev.table.data(), tbytes, hipMemcpyHostToDevice));
+    int occ = 0;
+    HIP_TRY(tgx::estep_max_blocks_per_cu(m->lm, &occ));
+    m->estep_blocks_per_cu = std::max(1, std::min(occ, 16));
+    return TGX_OK;
 }
 
 tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout,
                      uint64_t seed, double* expected, double* logz_sum) {
-    (void)m; (void)c; (void)snippet_len; (void)dropout; (void)seed; (void)expected; (void)logz_sum;
-    return fail(TGX_ERR_UNSUPPORTED, "tgx_estep: not implemented yet");
+    if (!m || !c || !expected) return fail(TGX_ERR_INVALID, "tgx_estep: NULL argument");
+    if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
+    if (snippet_len == 0) snippet_len = TGX_ESTEP_SNIPPET_LEN;
+    if (snippet_len >= 0xFFFFFF00ull) return fail(TGX_ERR_UNSUPPORTED, "snippet_len must be below 4 GiB");
+    std::lock_guard<std::mutex> lk(m->mu);
+    HIP_TRY(hipSetDevice(m->device));
+    tgx_status st = ensure_reverse_trie(m);
+    if (st != TGX_OK) return st;
+    m->n_timed = 0;
+    const uint64_t S = c->n_samples, N = c->n_bytes;
+    const size_t n_rev = m->flat_rev.table.size();
+    const size_t abytes = (size_t)(N + S + 128) * 8, ebytes = n_rev * 8 + 256;
+    double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr;
+    auto cleanup = [&](tgx_status s2) {
+        pool_free(m->device, d_alpha, abytes);
+        pool_free(m->device, d_exp, ebytes);
+        pool_free(m->device, d_z, 256);
+        return s2;
+    };
+    if (pool_alloc(m->device, abytes, (void**)&d_alpha) != hipSuccess ||
+        pool_alloc(m->device, ebytes, (void**)&d_exp) != hipSuccess ||
+        pool_alloc(m->device, 256, (void**)&d_z) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (E-step scratch)"));
+    if (hipMemsetAsync(d_exp, 0, ebytes, m->stream) != hipSuccess ||
+        hipMemsetAsync(d_z, 0, 256, m->stream) != hipSuccess ||
+        hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "memset failed"));
+    tgx::EstepParams p{};
+    p.text = c->d_text;
+    p.offs = c->d_offs;
+    p.order = c->d_order;
+    p.n_samples = S;
+    p.trie_fwd = m->d_trie;
+    p.trie_rev = m->d_trie_rev;
+    p.root_fwd = m->flat.table[0].base & ~tgx::kTerminalBit;
+    p.root_rev = m->flat_rev.table[0].base & ~tgx::kTerminalBit;
+    p.lm = m->lm;
+    p.snippet_len = snippet_len;
+    p.alpha = d_alpha;
+    p.expected_slot = d_exp;
+    p.logz_sum = d_z;
+    p.err_sample = m->d_ctrl + 1;
+    p.dropout = dropout;
+    p.seed = seed;
+    const uint64_t wpb = tgx::estep_waves_per_block(m->lm);
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(
+        1, std::min<uint64_t>((S + wpb - 1) / wpb, (uint64_t)m->num_cus * (uint64_t)m->estep_blocks_per_cu));
+    time_begin(m, "estep_kernel");
+    if (tgx::launch_estep(p, blocks, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "estep launch failed"));
+    time_end(m);
+    std::vector<double> h(n_rev);
+    double hz = 0.0;
+    if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(h.data(), d_exp, n_rev * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(&hz, d_z, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "E-step pass failed: %s", hipGetErrorString(hipGetLastError())));
+    for (size_t t = 0; t < n_rev; t++) {
+        const uint32_t id = m->flat_rev.tokid[t];
+        if (id != tgx::kNoToken) expected[id] += h[t];
+    }
+    if (logz_sum) *logz_sum = hz;
+    // N + 8(S+1) + 8V
+    m->last_alg_bytes = N + 8 * (S + 1) + 8ull * m->vocab_size;
+    const unsigned long long bad = m->h_ctrl[0];
+    if (bad != ~0ULL) {
+        g_err_sample = bad;
+        g_err_pos = g_err_len = c->h_offs[bad + 1] - c->h_offs[bad];
+        // the reference panics here: src/prune.rs:90-96
+        return cleanup(fail(TGX_ERR_Z_NOT_NORMAL, "normalization constant is not a normal number (sample %llu, len=%llu)",
+                            bad, (unsigned long long)g_err_len));
+    }
+    return cleanup(TGX_OK);
 }
 
 // ---- measurement ---------------------------------------------------------------
