@@ -101,14 +101,8 @@ def main() -> None:
     elapsed = time.perf_counter() - t_start
     alg_bytes = model.last_algorithmic_bytes()
 
-    tot_bytes, tot_tokens, max_elapsed = float(n_bytes), float(n_tokens), elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        max_elapsed = float(t.item())
-        s = torch.tensor([float(n_bytes), float(n_tokens)], dtype=torch.float64, device=f"cuda:{dev}")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        tot_bytes, tot_tokens = float(s[0].item()), float(s[1].item())
+    from tokengeex_amd import dist as tdist
+    max_elapsed, tot_bytes, tot_tokens = tdist.aggregate_timing(elapsed, n_bytes, n_tokens, dist, f"cuda:{dev}")
 
     if rank == 0:
         steps = max(1, args.steps)

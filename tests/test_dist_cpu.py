@@ -1,0 +1,74 @@
+"""world_size-2 gloo test of the multi-rank glue (sharding, rank-ordered count
+reduction, bench timing aggregation) on CPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle as orc
+from tokengeex_amd import dist as tdist
+from tokengeex_amd import synth
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flat, offs = synth.make_corpus(512 << 10, "mixed")
+        toks, scores = synth.build_vocab(flat, 1500, 12)
+        lo, hi = tdist.shard_bounds(offs, world)[rank]
+        sflat, soffs = tdist.take_shard(flat, offs, lo, hi)
+        model = orc.OracleModel(toks, scores)  # stands in for the per-GPU pass in this CPU-only test
+        freq = model.count_tokens_flat(sflat, soffs)
+        st, expected, z, _ = model.estep_flat(sflat, soffs)
+        tot_freq = tdist.allreduce_vector(freq, dist)
+        tot_exp = tdist.allreduce_vector(expected, dist)
+        elapsed, nb, nt = tdist.aggregate_timing(1.0 + rank, int(sflat.size), int(freq.sum()), dist)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), freq=tot_freq, exp=tot_exp, t=elapsed, nb=nb, nt=nt,
+                 lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_reduce(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    flat, offs = synth.make_corpus(512 << 10, "mixed")
+    toks, scores = synth.build_vocab(flat, 1500, 12)
+    model = orc.OracleModel(toks, scores)
+    # shards are contiguous, disjoint, cover everything, byte-balanced
+    assert (int(r0["lo"]), int(r1["hi"])) == (0, offs.size - 1) and int(r0["hi"]) == int(r1["lo"])
+    b0 = int(offs[int(r0["hi"])])
+    assert abs(b0 - flat.size / 2) < 70000
+    # integer counts: identical on both ranks and equal to the single-process pass
+    want = model.count_tokens_flat(flat, offs)
+    np.testing.assert_array_equal(r0["freq"], want)
+    np.testing.assert_array_equal(r1["freq"], want)
+    # f64 counts: rank-ordered sum -> bitwise identical on both ranks, equal to one pass up to rounding
+    np.testing.assert_array_equal(r0["exp"], r1["exp"])
+    _, exp1, _, _ = model.estep_flat(flat, offs)
+    np.testing.assert_allclose(r0["exp"], exp1, rtol=1e-12, atol=1e-12)
+    # bench aggregation: max of times, sums of units
+    assert float(r0["t"]) == 2.0 and float(r1["t"]) == 2.0
+    assert float(r0["nb"]) == float(flat.size) and float(r0["nt"]) == float(want.sum())
+
+
+def test_shard_bounds_edge_cases():
+    offs = np.array([0, 10, 10, 500, 1000], dtype=np.uint64)
+    assert tdist.shard_bounds(offs, 1) == [(0, 4)]
+    b = tdist.shard_bounds(offs, 3)
+    assert b[0][0] == 0 and b[-1][1] == 4 and all(b[i][1] == b[i + 1][0] for i in range(2))
+    b = tdist.shard_bounds(np.array([0, 5], dtype=np.uint64), 4)  # more ranks than samples
+    assert sum(hi - lo for lo, hi in b) == 1
