@@ -20,6 +20,7 @@ struct EncodeParams {
     uint32_t* bp;                   // u32[N] back-pointer scratch
     uint32_t* tmp;                  // u32[N] right-aligned ids per sample (MODE_ENCODE)
     uint32_t* counts;               // u32[S] tokens per sample
+    uint32_t* status;               // u32[S] 1 = end of sample reachable (encode4 -> trace)
     unsigned long long* freq;       // u64[V] histogram (MODE_COUNT)
     unsigned long long* next;       // work counter (zeroed before launch)
     unsigned long long* err_sample; // min failing sample (init ~0)
@@ -75,6 +76,10 @@ uint32_t encode_lds_bytes_per_block(uint32_t lm);
 uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out);
 hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
+uint32_t encode4_lds_bytes_per_block();
+hipError_t encode4_max_blocks_per_cu(bool dropout, int* out);
+hipError_t launch_encode4(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
+hipError_t launch_trace(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);
 hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);
 

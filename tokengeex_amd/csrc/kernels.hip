@@ -312,6 +312,205 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
     }
 }
 
+// ---- four samples per wave (max token length <= 16) -------------------------------
+// The relaxation of one sample keeps only <= 16 lanes busy, so the wave is split into
+// four 16-lane rows, each with its own sample, advancing in lock-step over blocks of
+// 16 positions.  Per step every VALU instruction now finalises FOUR positions: the
+// source position's best score and match mask are broadcast inside each row with DPP
+// (row_newbcast), lane l of a row accumulates the end position e ≡ l (mod 16), and a
+// token of length L pushes into lane (u + L) mod 16.  Same candidate order and strict
+// '>' as block_generic, hence the same bits.  Back-pointers and the per-sample
+// "end reachable" flag go to HBM; trace_kernel turns them into ids.
+template <int CTRL>
+__device__ __forceinline__ uint32_t row_bcast_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int U>
+__device__ __forceinline__ double row_bcast_f64(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = row_bcast_u32<0x150 + U>((uint32_t)b);
+    const uint32_t hi = row_bcast_u32<0x150 + U>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+constexpr uint64_t kRowLane0 = 0x0001000100010001ULL;  // lane 0 of each 16-lane row
+
+template <int U>
+__device__ __forceinline__ void relax4_step(const double* scr, const uint32_t* hlr, uint32_t lbit, uint32_t m_rot,
+                                            double& acc, uint32_t& bpv, uint32_t& fin, uint64_t& reach,
+                                            uint64_t& reached) {
+    constexpr uint64_t MU = kRowLane0 << U;                                   // lanes with l == U
+    constexpr uint64_t WRAPPED = (uint64_t)((1u << (U + 1)) - 1u) * kRowLane0;  // lanes with l <= U
+    fin = sel_u32(MU, bpv, fin);                     // back-pointer of position p0 + U is final now
+    reached |= reach & MU;                           // ... and so is whether it can be reached at all
+    const uint32_t m_eff = sel_u32(reach, m_rot, 0u);  // unreachable positions push nothing (model.rs:85-87)
+    const uint32_t mi = row_bcast_u32<0x150 + U>(m_eff);
+    const double best = row_bcast_f64<U>(acc);
+    const uint64_t active = __builtin_amdgcn_ballot_w64((mi & lbit) != 0u);
+    const uint32_t off = sel_u32(WRAPPED, 16u, 0u);
+    const double sv = scr[U * 15 + (int)off];
+    const uint32_t hv = hlr[U * 15 + (int)off];
+    const double cand = best + sv;  // model.rs:98
+    const uint64_t gt = __builtin_amdgcn_ballot_w64(cand > acc);
+    reach &= ~MU;  // lane U of each row now accumulates position p0 + U + 16
+    const uint64_t take = active & (~reach | gt);  // model.rs:101: empty, or strict '>'
+    acc = sel_f64(take, cand, acc);
+    bpv = sel_u32(take, hv, bpv);
+    reach |= active;
+}
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(256) void encode4_kernel(EncodeParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t LM = 16;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = lane & 15u, r = lane >> 4;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t entries = wave_lds_entries(LM);
+    unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(LM);
+    double* sc = reinterpret_cast<double*>(wbase);
+    uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + (size_t)entries * 8u);
+    const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
+
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint64_t n_rows = (uint64_t)gridDim.x * wpb * 4u;
+    uint64_t k = ((uint64_t)blockIdx.x * wpb + wave) * 4u + r;  // this row's next sample in the order
+
+    // per-row state (identical in the 16 lanes of a row)
+    uint32_t s = 0, n = 0, p0 = 0;
+    uint64_t beg = 0;
+    bool live = false, need_new = true;
+    double acc = 0.0;
+    uint32_t bpv = 0;
+    uint64_t reach = 0;  // wave-uniform: bit = lane holds a value
+
+    double* scw = sc + kFront + lane * LM;       // match writes: row = this lane, col = depth
+    uint32_t* hlw = hl + kFront + lane * LM;
+    const double* scr = sc + kFront + r * 256u + l - 1u;  // relax reads: + U*15 (+16 when wrapped)
+    const uint32_t* hlr = hl + kFront + r * 256u + l - 1u;
+    const uint32_t lbit = 1u << l;
+    const uint32_t rot = (l + 1u) & 15u;
+
+    for (;;) {
+        // ---- rows that finished their sample take the next one
+        if (need_new) {
+            live = k < P.n_samples;
+            if (live) {
+                s = P.order[k];
+                beg = P.offs[s];
+                n = (uint32_t)(P.offs[s + 1] - beg);
+                k += n_rows;
+            }
+            p0 = 0;
+            acc = 0.0;
+            bpv = 0;
+        }
+        const uint64_t fresh = __builtin_amdgcn_ballot_w64(need_new);
+        reach = (reach & ~fresh) | (fresh & kRowLane0);  // position 0: score 0, reachable
+        need_new = false;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // every row ran out of samples
+
+        // ---- match: 64 trie walks (4 rows x 16 positions)
+        const uint32_t p = p0 + l;
+        const uint32_t rem = (live && p < n) ? (n - p) : 0u;
+        const uint32_t maxd = rem < LM ? rem : LM;
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p : 0));
+        const uint32_t sh = (uint32_t)(addr & 3u);
+        const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
+        uint32_t w[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) w[q] = wp[q];
+        uint32_t bytes[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bytes[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh);
+
+        uint32_t cur = 0, base = P.root_base, m = 0;
+        bool alive = maxd > 0;
+        if (P.flags & 1u) {
+            alive = false;
+            m = maxd >= 3 ? 7u : (maxd ? 1u : 0u);
+        }
+#pragma unroll
+        for (int d = 0; d < (int)LM; ++d) {
+            alive = alive && ((uint32_t)d < maxd);
+            if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+            if (alive) {
+                const uint32_t c = (bytes[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+                const uint32_t t = base ^ c;
+                const uint4 rec = load_rec(trie, t);
+                alive = rec.x == cur;
+                if (alive) {
+                    cur = t;
+                    base = rec.y & 0x7FFFFFFFu;
+                    bool term = (rec.y >> 31) != 0u;
+                    if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
+                        if (term && d >= 1) term = P.dropout < dropout_u01(P.seed, s, p, (uint32_t)d + 1u);
+                    }
+                    if (term) {
+                        m |= 1u << d;
+                        scw[d] = __hiloint2double((int)rec.w, (int)rec.z);
+                        hlw[d] = (t << 6) | (uint32_t)d;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- relax: 16 static steps, four positions per step
+        uint32_t fin = 0;
+        uint64_t reached = 0;  // bit = that lane's position was reachable when it was finalised
+        if (!(P.flags & 2u)) {
+            // bit t of m_rot <-> target lane t of the row: token length L pushes into lane (l + L) & 15
+            const uint32_t m_rot = ((m << rot) | (m >> (16u - rot))) & 0xFFFFu;
+            relax4_step<0>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<1>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<2>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<3>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<4>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<5>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<6>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<7>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<8>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<9>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<10>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<11>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<12>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<13>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<14>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            relax4_step<15>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- back-pointers of positions p0 .. p0+15 (streamed past the caches), next block
+        if (live && p >= 1u && p <= n) __builtin_nontemporal_store(fin, P.bp + beg + p - 1);
+        if (live) {
+            const uint32_t left = n - p0;
+            if (left < 16u) {  // position n lies in this block: the sample is done
+                if (l == left) P.status[s] = (uint32_t)((reached >> lane) & 1ULL);
+                need_new = true;
+            } else {
+                p0 += 16u;
+            }
+        }
+    }
+}
+
+// Back-trace + id emission for samples whose back-pointers are already in HBM.
+template <int MODE>
+__global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint32_t n_waves = gridDim.x * wpb;
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+    for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
+        const uint64_t beg = first_u64(P.offs[s]);
+        const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
+        const uint32_t reach_n = (n == 0) ? 1u : (uint32_t)__builtin_amdgcn_readfirstlane((int)P.status[s]);
+        trace_sample<MODE>(P, s, beg, n, lane, P.bp + beg, reach_n);
+    }
+}
+
 // counts[S] -> offsets[S+1] (exclusive prefix sum), one workgroup.
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __restrict__ counts,
                                                            uint64_t* __restrict__ offsets,
@@ -405,6 +604,33 @@ hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, threads, lds);
+}
+
+// four-samples-per-wave path (max token length <= 16)
+uint32_t encode4_lds_bytes_per_block() { return 4u * wave_lds_bytes(16); }
+hipError_t encode4_max_blocks_per_cu(bool dropout, int* out) {
+    const uint32_t lds = encode4_lds_bytes_per_block();
+    const void* fn = dropout ? reinterpret_cast<const void*>(encode4_kernel<true>)
+                             : reinterpret_cast<const void*>(encode4_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return dropout ? hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode4_kernel<true>, 256, lds)
+                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode4_kernel<false>, 256, lds);
+}
+hipError_t launch_encode4(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {
+    const uint32_t lds = encode4_lds_bytes_per_block();
+    if (p.dropout > 0.0)
+        hipLaunchKernelGGL(encode4_kernel<true>, dim3(blocks), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL(encode4_kernel<false>, dim3(blocks), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_trace(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream) {
+    if (mode == MODE_ENCODE)
+        hipLaunchKernelGGL(trace_kernel<MODE_ENCODE>, dim3(blocks), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(trace_kernel<MODE_COUNT>, dim3(blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream) {

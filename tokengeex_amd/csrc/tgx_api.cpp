@@ -117,6 +117,7 @@ struct tgx_model {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     int blocks_per_cu[2] = {0, 0};
+    int blocks4_per_cu[2] = {0, 0};  // encode4_kernel<dropout = false / true>
     // E-step only (built on first use): trie of the reversed tokens
     std::vector<uint8_t> vocab_bytes;
     std::vector<uint64_t> vocab_offs;
@@ -140,6 +141,7 @@ struct tgx_corpus {
     uint32_t* d_bp = nullptr;      // scratch, allocated on first pass
     uint32_t* d_tmp = nullptr;
     uint32_t* d_counts = nullptr;
+    uint32_t* d_status = nullptr;
 };
 
 struct tgx_result {
@@ -202,6 +204,7 @@ tgx_status ensure_scratch(tgx_corpus* c) {
     HIP_TRY(pool_alloc(c->device, (size_t)c->n_bytes * 4 + 256, (void**)&c->d_bp));
     HIP_TRY(pool_alloc(c->device, (size_t)c->n_bytes * 4 + 256, (void**)&c->d_tmp));
     HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_counts));
+    HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_status));
     return TGX_OK;
 }
 
@@ -233,6 +236,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     p.bp = c->d_bp;
     p.tmp = c->d_tmp;
     p.counts = c->d_counts;
+    p.status = c->d_status;
     p.freq = d_freq;
     p.next = m->d_ctrl;
     p.err_sample = m->d_ctrl + 1;
@@ -242,14 +246,29 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
         const char* f = getenv("TGX_FLAGS");  // timing experiments only; results are wrong when set
         p.flags = f ? (uint32_t)atoi(f) : 0u;
     }
+    // TGX_PATH=fused forces the one-sample-per-wave kernel (A/B timing, tests of both paths)
+    const char* force = getenv("TGX_PATH");
+    const bool use4 = m->lm <= 16 && !(force && strcmp(force, "fused") == 0);
     if (debug_on())
-        fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u blocks=%u lds=%u slots=%zu root_base=%u\n",
-                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm,
-                grid_blocks(m, mode, c->n_samples), tgx::encode_lds_bytes_per_block(p.lm),
+        fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u\n",
+                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? "rows4" : "fused",
                 m->flat.table.size(), p.root_base);
-    time_begin(m, mode == tgx::MODE_ENCODE ? "encode_kernel" : "encode_count_kernel");
-    HIP_TRY(tgx::launch_encode(p, mode, grid_blocks(m, mode, c->n_samples), m->stream));
-    time_end(m);
+    if (use4) {
+        const uint64_t cap4 = (uint64_t)m->num_cus * (uint64_t)std::max(1, m->blocks4_per_cu[dropout > 0.0 ? 1 : 0]);
+        const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 15) / 16, cap4));
+        time_begin(m, "encode4_kernel");
+        HIP_TRY(tgx::launch_encode4(p, blocks4, m->stream));
+        time_end(m);
+        const uint32_t blocks_t =
+            (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
+        time_begin(m, mode == tgx::MODE_ENCODE ? "trace_kernel" : "trace_count_kernel");
+        HIP_TRY(tgx::launch_trace(p, mode, blocks_t, m->stream));
+        time_end(m);
+    } else {
+        time_begin(m, mode == tgx::MODE_ENCODE ? "encode_kernel" : "encode_count_kernel");
+        HIP_TRY(tgx::launch_encode(p, mode, grid_blocks(m, mode, c->n_samples), m->stream));
+        time_end(m);
+    }
     return TGX_OK;
 }
 
@@ -353,6 +372,11 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
         int occ = 0;
         HIP_TRY_M(tgx::encode_max_blocks_per_cu(m->lm, mode, &occ));
         m->blocks_per_cu[mode] = std::max(1, std::min(occ, 16));
+    }
+    for (int d = 0; d < 2; d++) {
+        int occ = 0;
+        HIP_TRY_M(tgx::encode4_max_blocks_per_cu(d == 1, &occ));
+        m->blocks4_per_cu[d] = std::max(1, std::min(occ, 8));
     }
     HIP_TRY_M(hipStreamSynchronize(m->stream));
 #undef HIP_TRY_M
@@ -491,6 +515,7 @@ void tgx_corpus_free(tgx_corpus* c) {
     pool_free(c->device, c->d_bp, (size_t)c->n_bytes * 4 + 256);
     pool_free(c->device, c->d_tmp, (size_t)c->n_bytes * 4 + 256);
     pool_free(c->device, c->d_counts, (size_t)c->n_samples * 4 + 256);
+    pool_free(c->device, c->d_status, (size_t)c->n_samples * 4 + 256);
     delete c;
 }
 

@@ -9,13 +9,18 @@ vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
 toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
 flat, offs = synth.make_corpus(size << 20, "mixed", seed_offset=1000)
 m = tgx.NativeModel(toks, scores); c = tgx.NativeCorpus(flat, offs)
-names = {0: "full", 4: "no trace", 6: "match only", 5: "fake match + relax", 7: "fake match only (loop overhead)", 1: "fake match + relax + trace"}
+names = {0: "full", 6: "match only", 5: "fake match + relax", 7: "fake match only (loop overhead)"}
+paths = ["rows4", "fused"]
 for rnd in range(2):
+  for path in paths:
+    os.environ["TGX_PATH"] = path
     for fl, nm in names.items():
+        nm = path + " " + nm
         os.environ["TGX_FLAGS"] = str(fl)
         try:
             r = m.encode_corpus(c); r.free()
         except tgx.TokenGeeXError as e:
             pass
-        t = m.last_kernel_times().get("encode_kernel", -1)
-        print(f"round {rnd} flags={fl} {nm:34s} {t:8.3f} ms  {flat.size / t / 1e6:8.2f} GB/s", flush=True)
+        kt = m.last_kernel_times()
+        t = sum(v for k, v in kt.items() if k.startswith(("encode", "trace")))
+        print(f"round {rnd} flags={fl} {nm:34s} {t:8.3f} ms  {flat.size / t / 1e6:8.2f} GB/s  {kt}", flush=True)
