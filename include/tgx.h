@@ -99,6 +99,8 @@ uint64_t tgx_flat_trie_search(const tgx_flat_trie *t, const uint8_t *s, uint64_t
                               uint32_t *lens, uint64_t cap);
 void tgx_flat_trie_stats(const tgx_flat_trie *t, uint64_t *n_slots, uint64_t *n_nodes,
                          uint32_t *max_token_len);
+/* copies the slot table: check[n_slots], base_flags[n_slots] (bit 31 = terminal), tokid[n_slots] */
+void tgx_flat_trie_copy(const tgx_flat_trie *t, uint32_t *check, uint32_t *base_flags, uint32_t *tokid);
 /* out-of-line copy of tgx_dropout_u01 (below) for bindings that cannot inline C */
 double tgx_dropout_u01_host(uint64_t seed, uint64_t sample, uint64_t pos, uint32_t len);
 

@@ -39,6 +39,7 @@ SYMBOLS = {
     "tgx_flat_trie_free": (None, [_vp]),
     "tgx_flat_trie_search": (_u64, [_vp, _vp, _u64, _vp, _vp, _u64]),
     "tgx_flat_trie_stats": (None, [_vp, _pu64, _pu64, C.POINTER(C.c_uint32)]),
+    "tgx_flat_trie_copy": (None, [_vp, _vp, _vp, _vp]),
     "tgx_dropout_u01_host": (_d, [_u64, _u64, _u64, _u32]),
     "tgx_encode_batch": (_i, [_vp, _vp, _vp, _u64, _d, _u64, _pvp]),
     "tgx_result_num_samples": (_u64, [_vp]),
@@ -315,6 +316,13 @@ class FlatTrie:
     @property
     def max_token_len(self) -> int:
         return self.stats()["max_token_len"]
+
+    def table(self):
+        """-> (check, base_flags, tokid) uint32 arrays of n_slots entries."""
+        n = self.stats()["n_slots"]
+        check, base, tokid = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        lib.tgx_flat_trie_copy(self._h, ptr(check), ptr(base), ptr(tokid))
+        return check, base, tokid
 
 
 def dropout_u01(seed: int, sample: int, pos: int, length: int) -> float:

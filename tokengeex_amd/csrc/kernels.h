@@ -16,6 +16,7 @@ struct EncodeParams {
     const uint32_t* tokid;          // u32[n_slots]
     uint32_t root_base;
     uint32_t n_slots;               // trie slots (guards the handle -> id lookup)
+    uint32_t cache_slots;           // rows4: leading trie slots staged in LDS
     uint32_t lm;                    // max token length rounded up (<= 64)
     uint32_t* bp;                   // u32[N] back-pointer scratch
     uint32_t* tmp;                  // u32[N] right-aligned ids per sample (MODE_ENCODE)
@@ -67,6 +68,13 @@ hipError_t pair_rle(void* temp, size_t temp_bytes, const unsigned long long* sor
                     unsigned long long* unique_out, unsigned int* counts_out, unsigned int* n_runs_out,
                     hipStream_t stream);
 
+hipError_t ids_sort_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t ids_sort(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint64_t n,
+                    unsigned int end_bit, hipStream_t stream);
+hipError_t ids_rle_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t ids_rle(void* temp, size_t temp_bytes, const uint32_t* sorted, uint64_t n, uint32_t* unique_out,
+                   unsigned int* counts_out, unsigned int* n_runs_out, hipStream_t stream);
+
 uint32_t estep_lds_bytes_per_block(uint32_t lm);
 uint32_t estep_waves_per_block(uint32_t lm);
 hipError_t estep_max_blocks_per_cu(uint32_t lm, int* out);
@@ -76,9 +84,10 @@ uint32_t encode_lds_bytes_per_block(uint32_t lm);
 uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out);
 hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
-uint32_t encode4_lds_bytes_per_block();
-hipError_t encode4_max_blocks_per_cu(bool dropout, int* out);
-hipError_t launch_encode4(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
+uint32_t encode4_cache_slots(int waves, int ppl, int bpc, uint32_t n_slots);
+uint32_t encode4_lds_bytes(int waves, int ppl, uint32_t cache_slots);
+hipError_t encode4_prepare(bool dropout, int ppl);
+hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream);
 hipError_t launch_trace(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);
 hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);

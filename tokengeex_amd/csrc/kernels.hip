@@ -335,21 +335,24 @@ __device__ __forceinline__ double row_bcast_f64(double v) {
 
 constexpr uint64_t kRowLane0 = 0x0001000100010001ULL;  // lane 0 of each 16-lane row
 
+// LDS layout of a 16-position group (rows4): entry (row, len - 1) lives at column
+// (len - 1 + row) & 15 of its row (row = lane that matched it).  The target lane
+// l = (u + len) & 15 of step u then always reads column (l - 1) & 15 — a per-lane
+// constant, so relax reads need no address arithmetic — and the 64 match-phase writers
+// of one depth spread over 16 columns instead of hitting one bank.
 template <int U>
 __device__ __forceinline__ void relax4_step(const double* scr, const uint32_t* hlr, uint32_t lbit, uint32_t m_rot,
                                             double& acc, uint32_t& bpv, uint32_t& fin, uint64_t& reach,
                                             uint64_t& reached) {
-    constexpr uint64_t MU = kRowLane0 << U;                                   // lanes with l == U
-    constexpr uint64_t WRAPPED = (uint64_t)((1u << (U + 1)) - 1u) * kRowLane0;  // lanes with l <= U
+    constexpr uint64_t MU = kRowLane0 << U;          // lanes with l == U
     fin = sel_u32(MU, bpv, fin);                     // back-pointer of position p0 + U is final now
     reached |= reach & MU;                           // ... and so is whether it can be reached at all
     const uint32_t m_eff = sel_u32(reach, m_rot, 0u);  // unreachable positions push nothing (model.rs:85-87)
     const uint32_t mi = row_bcast_u32<0x150 + U>(m_eff);
     const double best = row_bcast_f64<U>(acc);
     const uint64_t active = __builtin_amdgcn_ballot_w64((mi & lbit) != 0u);
-    const uint32_t off = sel_u32(WRAPPED, 16u, 0u);
-    const double sv = scr[U * 15 + (int)off];
-    const uint32_t hv = hlr[U * 15 + (int)off];
+    const double sv = scr[U * 16];
+    const uint32_t hv = hlr[U * 16];
     const double cand = best + sv;  // model.rs:98
     const uint64_t gt = __builtin_amdgcn_ballot_w64(cand > acc);
     reach &= ~MU;  // lane U of each row now accumulates position p0 + U + 16
@@ -359,18 +362,29 @@ __device__ __forceinline__ void relax4_step(const double* scr, const uint32_t* h
     reach |= active;
 }
 
-template <bool DROPOUT>
-__global__ __launch_bounds__(256) void encode4_kernel(EncodeParams P) {
+// rows4 LDS: 1024 (score, handle) entries per wave and 16-position group, and — shared
+// by all waves of the block — the first P.cache_slots records of the trie.  With the
+// hottest-first slot order those take ~80 % of all trie gathers at 4096 slots (64 KiB),
+// which would otherwise queue in the CU's vector L1.  One block per CU.
+constexpr uint32_t kRows4Entries = 1024;
+constexpr uint32_t kRows4GroupBytes = kRows4Entries * 12u;  // 12288
+
+// PPL = positions per lane and iteration: a row advances 16*PPL positions per trip of
+// the dependent gather chain.
+template <bool DROPOUT, int PPL>
+__global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
+    constexpr uint32_t SPAN = 16u * PPL;  // positions per row and iteration
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t entries = wave_lds_entries(LM);
-    unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(LM);
-    double* sc = reinterpret_cast<double*>(wbase);
-    uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + (size_t)entries * 8u);
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
+    const uint32_t K = P.cache_slots;
+    uint4* tcache = reinterpret_cast<uint4*>(smem);
+    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) tcache[i] = trie[i];
+    __syncthreads();
+    unsigned char* wbase = smem + (size_t)K * 16u + (size_t)wave * (PPL * kRows4GroupBytes);
 
     const uint32_t wpb = blockDim.x >> 6;
     const uint64_t n_rows = (uint64_t)gridDim.x * wpb * 4u;
@@ -384,10 +398,6 @@ __global__ __launch_bounds__(256) void encode4_kernel(EncodeParams P) {
     uint32_t bpv = 0;
     uint64_t reach = 0;  // wave-uniform: bit = lane holds a value
 
-    double* scw = sc + kFront + lane * LM;       // match writes: row = this lane, col = depth
-    uint32_t* hlw = hl + kFront + lane * LM;
-    const double* scr = sc + kFront + r * 256u + l - 1u;  // relax reads: + U*15 (+16 when wrapped)
-    const uint32_t* hlr = hl + kFront + r * 256u + l - 1u;
     const uint32_t lbit = 1u << l;
     const uint32_t rot = (l + 1u) & 15u;
 
@@ -410,86 +420,128 @@ __global__ __launch_bounds__(256) void encode4_kernel(EncodeParams P) {
         need_new = false;
         if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // every row ran out of samples
 
-        // ---- match: 64 trie walks (4 rows x 16 positions)
-        const uint32_t p = p0 + l;
-        const uint32_t rem = (live && p < n) ? (n - p) : 0u;
-        const uint32_t maxd = rem < LM ? rem : LM;
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p : 0));
+        // ---- match: 64*PPL trie walks; lane (r, l) owns positions p0 + 16*g + l, g < PPL
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p0 + l : 0));
         const uint32_t sh = (uint32_t)(addr & 3u);
         const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
-        uint32_t w[5];
+        uint32_t w[4 * PPL + 1];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) w[q] = wp[q];
-        uint32_t bytes[4];
+        for (int q = 0; q <= 4 * PPL; ++q) w[q] = wp[q];
+        uint32_t bytes[PPL][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bytes[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh);
+        for (int g = 0; g < PPL; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bytes[g][q] = __builtin_amdgcn_alignbyte(w[4 * g + q + 1], w[4 * g + q], sh);
 
-        uint32_t cur = 0, base = P.root_base, m = 0;
-        bool alive = maxd > 0;
-        if (P.flags & 1u) {
-            alive = false;
-            m = maxd >= 3 ? 7u : (maxd ? 1u : 0u);
+        uint32_t pg[PPL], maxd[PPL], cur[PPL], base[PPL], m[PPL];
+        bool alive[PPL];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            pg[g] = p0 + 16u * g + l;
+            const uint32_t rem = (live && pg[g] < n) ? (n - pg[g]) : 0u;
+            maxd[g] = rem < LM ? rem : LM;
+            cur[g] = 0;
+            base[g] = P.root_base;
+            m[g] = 0;
+            alive[g] = maxd[g] > 0;
+            if (P.flags & 1u) {
+                alive[g] = false;
+                m[g] = maxd[g] >= 3 ? 7u : (maxd[g] ? 1u : 0u);
+            }
         }
 #pragma unroll
         for (int d = 0; d < (int)LM; ++d) {
-            alive = alive && ((uint32_t)d < maxd);
-            if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
-            if (alive) {
-                const uint32_t c = (bytes[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
-                const uint32_t t = base ^ c;
-                const uint4 rec = load_rec(trie, t);
-                alive = rec.x == cur;
-                if (alive) {
-                    cur = t;
-                    base = rec.y & 0x7FFFFFFFu;
-                    bool term = (rec.y >> 31) != 0u;
-                    if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
-                        if (term && d >= 1) term = P.dropout < dropout_u01(P.seed, s, p, (uint32_t)d + 1u);
-                    }
-                    if (term) {
-                        m |= 1u << d;
-                        scw[d] = __hiloint2double((int)rec.w, (int)rec.z);
-                        hlw[d] = (t << 6) | (uint32_t)d;
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < PPL; ++g) {
+                alive[g] = alive[g] && ((uint32_t)d < maxd[g]);
+                any = any || alive[g];
+            }
+            if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+            if (any) {
+                // all of this lane's gathers of the step are issued before any is consumed
+                uint4 rec[PPL];
+                uint32_t t[PPL];
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) {
+                    const uint32_t c = (bytes[g][d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+                    t[g] = alive[g] ? (base[g] ^ c) : 0u;
+                    if (t[g] < K)
+                        rec[g] = tcache[t[g]];
+                    else
+                        rec[g] = trie[t[g]];
+                }
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) asm volatile("" : "+v"(rec[g].x), "+v"(rec[g].y), "+v"(rec[g].z), "+v"(rec[g].w));
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) {
+                    alive[g] = alive[g] && rec[g].x == cur[g];
+                    if (alive[g]) {
+                        cur[g] = t[g];
+                        base[g] = rec[g].y & 0x7FFFFFFFu;
+                        bool term = (rec[g].y >> 31) != 0u;
+                        if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
+                            if (term && d >= 1) term = P.dropout < dropout_u01(P.seed, s, pg[g], (uint32_t)d + 1u);
+                        }
+                        if (term) {
+                            double* scw = reinterpret_cast<double*>(wbase + g * kRows4GroupBytes) + lane * LM;
+                            uint32_t* hlw = reinterpret_cast<uint32_t*>(wbase + g * kRows4GroupBytes + kRows4Entries * 8u) + lane * LM;
+                            const uint32_t col = ((uint32_t)d + l) & 15u;  // (len - 1 + row) & 15
+                            m[g] |= 1u << d;
+                            scw[col] = __hiloint2double((int)rec[g].w, (int)rec[g].z);
+                            hlw[col] = (t[g] << 6) | (uint32_t)d;
+                        }
                     }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- relax: 16 static steps, four positions per step
-        uint32_t fin = 0;
-        uint64_t reached = 0;  // bit = that lane's position was reachable when it was finalised
-        if (!(P.flags & 2u)) {
+        // ---- relax: 16*PPL static steps, four positions (one per row) per step
+        uint32_t fin[PPL];
+        uint64_t reached[PPL];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            fin[g] = 0;
+            reached[g] = 0;  // bit = that lane's position was reachable when it was finalised
+            if (P.flags & 2u) continue;
+            // row (r*16 + U), column (l - 1) & 15: see relax4_step
+            const double* scr = reinterpret_cast<const double*>(wbase + g * kRows4GroupBytes) + r * 256u + ((l - 1u) & 15u);
+            const uint32_t* hlr = reinterpret_cast<const uint32_t*>(wbase + g * kRows4GroupBytes + kRows4Entries * 8u) + r * 256u + ((l - 1u) & 15u);
             // bit t of m_rot <-> target lane t of the row: token length L pushes into lane (l + L) & 15
-            const uint32_t m_rot = ((m << rot) | (m >> (16u - rot))) & 0xFFFFu;
-            relax4_step<0>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<1>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<2>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<3>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<4>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<5>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<6>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<7>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<8>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<9>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<10>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<11>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<12>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<13>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<14>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
-            relax4_step<15>(scr, hlr, lbit, m_rot, acc, bpv, fin, reach, reached);
+            const uint32_t m_rot = ((m[g] << rot) | (m[g] >> (16u - rot))) & 0xFFFFu;
+            relax4_step<0>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<1>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<2>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<3>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<4>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<5>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<6>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<7>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<8>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<9>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<10>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<11>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<12>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<13>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<14>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            relax4_step<15>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- back-pointers of positions p0 .. p0+15 (streamed past the caches), next block
-        if (live && p >= 1u && p <= n) __builtin_nontemporal_store(fin, P.bp + beg + p - 1);
+        // ---- back-pointers of the SPAN positions (streamed past the caches), next block
+#pragma unroll
+        for (int g = 0; g < PPL; ++g)
+            if (live && pg[g] >= 1u && pg[g] <= n) __builtin_nontemporal_store(fin[g], P.bp + beg + pg[g] - 1);
         if (live) {
             const uint32_t left = n - p0;
-            if (left < 16u) {  // position n lies in this block: the sample is done
-                if (l == left) P.status[s] = (uint32_t)((reached >> lane) & 1ULL);
+            if (left < SPAN) {  // position n lies in this iteration: the sample is done
+#pragma unroll
+                for (int g = 0; g < PPL; ++g)
+                    if (left == 16u * g + l) P.status[s] = (uint32_t)((reached[g] >> lane) & 1ULL);
                 need_new = true;
             } else {
-                p0 += 16u;
+                p0 += SPAN;
             }
         }
     }
@@ -606,23 +658,32 @@ hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, threads, lds);
 }
 
-// four-samples-per-wave path (max token length <= 16)
-uint32_t encode4_lds_bytes_per_block() { return 4u * wave_lds_bytes(16); }
-hipError_t encode4_max_blocks_per_cu(bool dropout, int* out) {
-    const uint32_t lds = encode4_lds_bytes_per_block();
-    const void* fn = dropout ? reinterpret_cast<const void*>(encode4_kernel<true>)
-                             : reinterpret_cast<const void*>(encode4_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    return dropout ? hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode4_kernel<true>, 256, lds)
-                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(out, encode4_kernel<false>, 256, lds);
+// four-samples-per-wave path (max token length <= 16): one block per CU
+typedef void (*encode4_fn)(EncodeParams);
+static encode4_fn pick_encode4(bool dropout, int ppl) {
+    if (ppl == 1) return dropout ? encode4_kernel<true, 1> : encode4_kernel<false, 1>;
+    if (ppl == 2) return dropout ? encode4_kernel<true, 2> : encode4_kernel<false, 2>;
+    return dropout ? encode4_kernel<true, 4> : encode4_kernel<false, 4>;
 }
-hipError_t launch_encode4(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {
-    const uint32_t lds = encode4_lds_bytes_per_block();
-    if (p.dropout > 0.0)
-        hipLaunchKernelGGL(encode4_kernel<true>, dim3(blocks), dim3(256), lds, stream, p);
-    else
-        hipLaunchKernelGGL(encode4_kernel<false>, dim3(blocks), dim3(256), lds, stream, p);
+// LDS split: `bpc` blocks per CU share its 160 KiB; what a block's waves do not need for
+// their match groups caches the leading trie slots (whole 256-slot XOR blocks).
+uint32_t encode4_cache_slots(int waves, int ppl, int bpc, uint32_t n_slots) {
+    const uint32_t total = (160u * 1024u) / (uint32_t)bpc;
+    const uint32_t groups = (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes;
+    uint32_t k = groups < total ? (total - groups) / 16u : 0u;
+    k &= ~255u;
+    return k < n_slots ? k : (n_slots & ~255u);
+}
+uint32_t encode4_lds_bytes(int waves, int ppl, uint32_t cache_slots) {
+    return cache_slots * 16u + (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes;
+}
+hipError_t encode4_prepare(bool dropout, int ppl) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(pick_encode4(dropout, ppl)),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(pick_encode4(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * (uint32_t)waves),
+                       encode4_lds_bytes(waves, ppl, p.cache_slots), stream, p);
     return hipGetLastError();
 }
 hipError_t launch_trace(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream) {

@@ -68,4 +68,31 @@ hipError_t pair_rle(void* temp, size_t temp_bytes, const unsigned long long* sor
                                       n_runs_out, stream);
 }
 
+// ---- token histogram (frequency pass, src/prune.rs:205-244) by sort + run-length encode:
+// global atomics on a Zipf-distributed id stream serialise on the hot tokens.
+hipError_t ids_sort_temp_bytes(uint64_t n, size_t* bytes) {
+    uint32_t* p = nullptr;
+    size_t b = 0;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, b, p, p, (size_t)n);
+    *bytes = b;
+    return e;
+}
+hipError_t ids_sort(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint64_t n,
+                    unsigned int end_bit, hipStream_t stream) {
+    return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, end_bit, stream);
+}
+hipError_t ids_rle_temp_bytes(uint64_t n, size_t* bytes) {
+    uint32_t* p = nullptr;
+    unsigned int* c = nullptr;
+    size_t b = 0;
+    hipError_t e = rocprim::run_length_encode(nullptr, b, p, (unsigned int)n, p, c, c);
+    *bytes = b;
+    return e;
+}
+hipError_t ids_rle(void* temp, size_t temp_bytes, const uint32_t* sorted, uint64_t n, uint32_t* unique_out,
+                   unsigned int* counts_out, unsigned int* n_runs_out, hipStream_t stream) {
+    return rocprim::run_length_encode(temp, temp_bytes, sorted, (unsigned int)n, unique_out, counts_out,
+                                      n_runs_out, stream);
+}
+
 }  // namespace tgx

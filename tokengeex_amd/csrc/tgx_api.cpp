@@ -117,7 +117,6 @@ struct tgx_model {
     hipStream_t stream = nullptr;
     int num_cus = 0;
     int blocks_per_cu[2] = {0, 0};
-    int blocks4_per_cu[2] = {0, 0};  // encode4_kernel<dropout = false / true>
     // E-step only (built on first use): trie of the reversed tokens
     std::vector<uint8_t> vocab_bytes;
     std::vector<uint64_t> vocab_offs;
@@ -254,10 +253,28 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
                 (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? "rows4" : "fused",
                 m->flat.table.size(), p.root_base);
     if (use4) {
-        const uint64_t cap4 = (uint64_t)m->num_cus * (uint64_t)std::max(1, m->blocks4_per_cu[dropout > 0.0 ? 1 : 0]);
-        const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 15) / 16, cap4));
+        // `bpc` blocks per CU of `waves` waves each; LDS left over caches the hottest trie
+        // slots.  TGX_PPL (positions per lane: 1, 2, 4), TGX_WAVES, TGX_BPC override the defaults.
+        int ppl = 1, waves = 4, bpc = 3;
+        if (const char* e = getenv("TGX_PPL")) {
+            const int v = atoi(e);
+            if (v == 1 || v == 2 || v == 4) ppl = v;
+        }
+        if (const char* e = getenv("TGX_WAVES")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 16) waves = v;
+        }
+        if (const char* e = getenv("TGX_BPC")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8) bpc = v;
+        }
+        while (waves > 1 && (uint32_t)(waves * ppl) * 12288u > (160u * 1024u) / (uint32_t)bpc) waves--;
+        p.cache_slots = tgx::encode4_cache_slots(waves, ppl, bpc, p.n_slots);
+        const uint64_t rows_per_block = 4 * (uint64_t)waves;
+        const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
+            1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
         time_begin(m, "encode4_kernel");
-        HIP_TRY(tgx::launch_encode4(p, blocks4, m->stream));
+        HIP_TRY(tgx::launch_encode4(p, ppl, waves, blocks4, m->stream));
         time_end(m);
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
@@ -373,11 +390,8 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
         HIP_TRY_M(tgx::encode_max_blocks_per_cu(m->lm, mode, &occ));
         m->blocks_per_cu[mode] = std::max(1, std::min(occ, 16));
     }
-    for (int d = 0; d < 2; d++) {
-        int occ = 0;
-        HIP_TRY_M(tgx::encode4_max_blocks_per_cu(d == 1, &occ));
-        m->blocks4_per_cu[d] = std::max(1, std::min(occ, 8));
-    }
+    for (int d = 0; d < 2; d++)
+        for (int q = 0; q < 3; q++) HIP_TRY_M(tgx::encode4_prepare(d == 1, 1 << q));
     HIP_TRY_M(hipStreamSynchronize(m->stream));
 #undef HIP_TRY_M
     *out = m;
@@ -441,6 +455,14 @@ void tgx_flat_trie_stats(const tgx_flat_trie* t, uint64_t* n_slots, uint64_t* n_
     if (n_slots) *n_slots = t->flat.table.size();
     if (n_nodes) *n_nodes = t->flat.n_nodes;
     if (max_token_len) *max_token_len = t->flat.max_token_len;
+}
+void tgx_flat_trie_copy(const tgx_flat_trie* t, uint32_t* check, uint32_t* base_flags, uint32_t* tokid) {
+    if (!t) return;
+    for (size_t i = 0; i < t->flat.table.size(); i++) {
+        if (check) check[i] = t->flat.table[i].check;
+        if (base_flags) base_flags[i] = t->flat.table[i].base;
+        if (tokid) tokid[i] = t->flat.tokid[i];
+    }
 }
 double tgx_dropout_u01_host(uint64_t seed, uint64_t sample, uint64_t pos, uint32_t len) {
     return tgx_dropout_u01(seed, sample, pos, len);
@@ -650,27 +672,57 @@ tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
     if (!m || !c || !freq) return fail(TGX_ERR_INVALID, "tgx_count_tokens: NULL argument");
     if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
     std::lock_guard<std::mutex> lk(m->mu);
-    HIP_TRY(hipSetDevice(m->device));
-    m->n_timed = 0;
-    const size_t fbytes = (size_t)m->vocab_size * 8 + 256;
-    unsigned long long* d_freq = nullptr;
-    HIP_TRY(pool_alloc(m->device, fbytes, (void**)&d_freq));
-    auto cleanup = [&](tgx_status st) {
-        pool_free(m->device, d_freq, fbytes);
-        return st;
+    // model.encode(sample, 0.0) for every sample (src/prune.rs:218), then a histogram of the ids by
+    // radix sort + run-length encode
+    tgx_result* r = nullptr;
+    tgx_status st = encode_corpus_locked(m, c, 0.0, 0, &r);
+    if (st != TGX_OK) return st;
+    const uint64_t T = r->n_tokens;
+    if (T >= 0xFFFFFFFFull) {
+        tgx_result_free(r);
+        return fail(TGX_ERR_UNSUPPORTED, "frequency pass over more than 2^32-1 tokens per call");
+    }
+    uint32_t *d_sorted = nullptr, *d_unique = nullptr;
+    unsigned int *d_cnt = nullptr, *d_runs = nullptr;
+    void* d_temp = nullptr;
+    size_t tb1 = 0, tb2 = 0;
+    const size_t kb = (size_t)T * 4 + 256;
+    auto cleanup = [&](tgx_status s2) {
+        pool_free(m->device, d_sorted, kb);
+        pool_free(m->device, d_unique, kb);
+        pool_free(m->device, d_cnt, kb);
+        pool_free(m->device, d_runs, 256);
+        pool_free(m->device, d_temp, std::max(tb1, tb2) + 256);
+        tgx_result_free(r);
+        return s2;
     };
-    if (hipMemsetAsync(d_freq, 0, fbytes, m->stream) != hipSuccess)
-        return cleanup(fail(TGX_ERR_DEVICE, "memset failed"));
-    tgx_status st = run_encode_kernel(m, c, tgx::MODE_COUNT, 0.0, 0, d_freq);
-    if (st != TGX_OK) return cleanup(st);
-    std::vector<unsigned long long> h(m->vocab_size ? m->vocab_size : 1);
-    if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
-        hipMemcpyAsync(h.data(), d_freq, (size_t)m->vocab_size * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+    if (T == 0) return cleanup(TGX_OK);
+    if (tgx::ids_sort_temp_bytes(T, &tb1) != hipSuccess || tgx::ids_rle_temp_bytes(T, &tb2) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "rocPRIM temp-size query failed"));
+    if (pool_alloc(m->device, kb, (void**)&d_sorted) != hipSuccess ||
+        pool_alloc(m->device, kb, (void**)&d_unique) != hipSuccess ||
+        pool_alloc(m->device, kb, (void**)&d_cnt) != hipSuccess ||
+        pool_alloc(m->device, 256, (void**)&d_runs) != hipSuccess ||
+        pool_alloc(m->device, std::max(tb1, tb2) + 256, &d_temp) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (frequency pass)"));
+    unsigned int end_bit = 1;
+    while (end_bit < 32 && (1ull << end_bit) < (uint64_t)m->vocab_size) end_bit++;
+    time_begin(m, "ids_sort+rle");
+    if (tgx::ids_sort(d_temp, tb1, r->d_ids, d_sorted, T, end_bit, m->stream) != hipSuccess ||
+        tgx::ids_rle(d_temp, tb2, d_sorted, T, d_unique, d_cnt, d_runs, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "id sort / run-length encode failed"));
+    time_end(m);
+    unsigned int runs = 0;
+    if (hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipStreamSynchronize(m->stream) != hipSuccess)
-        return cleanup(fail(TGX_ERR_DEVICE, "count pass failed: %s", hipGetErrorString(hipGetLastError())));
-    st = check_no_path(m, c);
-    if (st != TGX_OK) return cleanup(st);
-    for (uint32_t i = 0; i < m->vocab_size; i++) freq[i] += h[i];
+        return cleanup(fail(TGX_ERR_DEVICE, "frequency pass failed: %s", hipGetErrorString(hipGetLastError())));
+    std::vector<uint32_t> hu(runs ? runs : 1);
+    std::vector<unsigned int> hc(runs ? runs : 1);
+    if (runs && (hipMemcpy(hu.data(), d_unique, (size_t)runs * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                 hipMemcpy(hc.data(), d_cnt, (size_t)runs * 4, hipMemcpyDeviceToHost) != hipSuccess))
+        return cleanup(fail(TGX_ERR_DEVICE, "D2H copy of the histogram failed"));
+    for (unsigned int i = 0; i < runs; i++)
+        if (hu[i] < m->vocab_size) freq[hu[i]] += hc[i];
     m->last_alg_bytes = c->n_bytes + 8 * (c->n_samples + 1) + 8ull * m->vocab_size;
     return cleanup(TGX_OK);
 }

@@ -1,7 +1,9 @@
 #include "trie_build.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <queue>
 
 namespace tgx {
 
@@ -119,16 +121,33 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     for (const Edge& e : edges) row[e.parent + 1]++;
     for (uint32_t i = 0; i < n_nodes; i++) row[i + 1] += row[i];
 
-    // 3. breadth-first slot assignment (hot top levels land in the first blocks).
+    // 3. hottest-first slot assignment.  A node's weight is the probability mass of the
+    // tokens below it (sum of exp(score)), a proxy for how often a walk passes through it;
+    // nodes are expanded in descending weight, so the children blocks of the most
+    // visited nodes land in the first slots (the kernels keep those in LDS).
+    std::vector<double> weight(n_nodes, 0.0);
+    for (uint32_t i = 0; i < n_nodes; i++)
+        if (node_tok[i] != kNoToken) {
+            const double w = std::exp(scores[node_tok[i]]);
+            weight[i] = (w == w && w < 1e300) ? w : 0.0;
+        }
+    {
+        std::vector<uint32_t> parent(n_nodes, 0);
+        for (const Edge& e : edges) parent[e.child] = e.parent;
+        for (uint32_t i = n_nodes; i-- > 1;) weight[parent[i]] += weight[i];  // children are created after parents
+    }
     BlockAlloc ba;
     ba.add_block();
     ba.mark(0);  // root
     std::vector<uint32_t> slot(n_nodes, 0), base(n_nodes, 0);
-    std::vector<uint32_t> queue;
-    queue.reserve(n_nodes);
-    queue.push_back(0);
-    for (size_t qi = 0; qi < queue.size(); qi++) {
-        uint32_t node = queue[qi];
+    auto colder = [&weight](uint32_t a, uint32_t b) {
+        return weight[a] != weight[b] ? weight[a] < weight[b] : a > b;
+    };
+    std::priority_queue<uint32_t, std::vector<uint32_t>, decltype(colder)> queue(colder);
+    queue.push(0);
+    while (!queue.empty()) {
+        uint32_t node = queue.top();
+        queue.pop();
         uint32_t lo = row[node], hi = row[node + 1], k = hi - lo;
         if (k == 0) continue;
         uint32_t chosen = 0;
@@ -173,7 +192,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
             uint32_t t = chosen ^ edges[j].byte;
             ba.mark(t);
             slot[edges[j].child] = t;
-            queue.push_back(edges[j].child);
+            queue.push(edges[j].child);
         }
     }
 

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Collect PMC counters for the encode pass (one bench step per counter group).
+# usage: tools/pmc_encode.sh <outdir-under-gpurun_out> [extra bench args]
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$1; shift
+mkdir -p $OUT
+cd /tmp
+i=0
+for P in "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum" \
+         "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
+         "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum" \
+         "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 200 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" > $OUT/g$i.log 2>&1 || echo "group $i failed"
+done
+python3 - $OUT <<'PY'
+import csv, glob, collections, sys
+out = sys.argv[1]
+res = collections.defaultdict(dict)
+for d in sorted(glob.glob(out + "/g*/*/*_counter_collection.csv")):
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    with open(d) as f:
+        for row in csv.DictReader(f):
+            k = row["Kernel_Name"].split("(")[0].split("::")[-1][:28]
+            agg[(k, row["Counter_Name"])] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
+    for (k, c), v in agg.items():
+        res[k][c] = v / cnt[(k, c)]
+with open(out + "/summary.txt", "w") as f:
+    for k, v in res.items():
+        if k.startswith(("encode", "trace", "estep", "pair")):
+            f.write(k + "\n")
+            for c, x in sorted(v.items()):
+                f.write(f"    {c:42s} {x:18.1f}\n")
+print(open(out + "/summary.txt").read())
+PY
