@@ -51,7 +51,9 @@ def main() -> None:
     if rank == 0:
         entry.build()  # no-op when the in-tree .so files are current
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TGX_BENCH_FORCE_DIST") == "1":  # the env var rehearses the N > 1 path on one GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         import torch.distributed as dist_mod
         dist = dist_mod
         torch.cuda.set_device(local_rank)

@@ -172,3 +172,41 @@ def test_tokenizer_surface_on_gpu():
     assert tk2.encode_batch(["Hello world<EOS>"], 0.0) == tk.encode_batch(["Hello world<EOS>"], 0.0)
     with pytest.raises(tgx.TokenGeeXError):
         tgx.Tokenizer([(b"a", -1.0, False)]).encode("b", 0.0)
+
+
+def test_large_vocabularies_64k_and_200k():
+    """BASELINE configs[2] (64 K vocab, max token 16) and a prune-start sized vocabulary."""
+    flat, offs = synth.make_corpus(12 << 20, "mixed", seed_offset=77)
+    for size in (65536, 200000):
+        toks, scores = synth.build_vocab(flat[: 6 << 20], size, 16)
+        assert len(toks) == size
+        nat, ora = _pair(toks, scores)
+        sub_flat, sub_offs = flat[: int(offs[400])], offs[:401]
+        assert_same_encoding(nat, ora, sub_flat, sub_offs)
+        corpus = tgx.NativeCorpus(sub_flat, sub_offs)
+        np.testing.assert_array_equal(nat.count_tokens(corpus), ora.count_tokens_flat(sub_flat, sub_offs, threads=8))
+
+
+def test_both_kernel_paths_agree(monkeypatch):
+    """The four-samples-per-wave path and the one-sample-per-wave path (TGX_PATH=fused)."""
+    flat, offs, toks, scores = corpus_and_vocab(1 << 20, "mixed", 5000, 16, seed_offset=3)
+    nat, ora = _pair(toks, scores)
+    want_ids, want_offs = ora.encode_batch_flat(flat, offs, threads=8)
+    for path in ("rows4", "fused"):
+        monkeypatch.setenv("TGX_PATH", path)
+        res = nat.encode_batch_flat(flat, offs)
+        np.testing.assert_array_equal(res.ids(), want_ids)
+        np.testing.assert_array_equal(res.offsets(), want_offs)
+        assert ("encode4_kernel" in nat.last_kernel_times()) == (path == "rows4")
+
+
+def test_non_finite_scores_use_the_exact_generic_path():
+    # -inf / +inf / NaN scores are legal f64 values for the reference's DP (model.rs:98-101)
+    inf = float("inf")
+    toks = [b"a", b"b", b"ab", b"ba", b"c", b"abc"]
+    for scores in ([-1.0, -inf, -0.5, -2.0, -1.0, -3.0], [-1.0, -1.0, inf, -2.0, -1.0, -inf],
+                   [-1.0, float("nan"), -0.5, -2.0, -1.0, -1.0]):
+        nat, ora = _pair(toks, scores)
+        texts = [b"abcab", b"bbbb", b"abab" * 20, b"cab", b"b"]
+        assert _enc(nat, texts) == ora.encode_batch(texts), scores
+        assert "encode4_kernel" not in nat.last_kernel_times()

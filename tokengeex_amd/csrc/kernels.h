@@ -28,6 +28,7 @@ struct EncodeParams {
     double dropout;
     uint64_t seed;
     uint32_t flags;                 // timing experiments only (TGX_FLAGS env): see kernels.hip
+    unsigned long long* stamps;     // diagnostic build only (TGX_STAMPS=1): 8 u64 per wave
 };
 
 struct CompactParams {

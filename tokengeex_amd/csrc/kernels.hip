@@ -340,26 +340,27 @@ constexpr uint64_t kRowLane0 = 0x0001000100010001ULL;  // lane 0 of each 16-lane
 // l = (u + len) & 15 of step u then always reads column (l - 1) & 15 — a per-lane
 // constant, so relax reads need no address arithmetic — and the 64 match-phase writers
 // of one depth spread over 16 columns instead of hitting one bank.
+//
+// "No token" is encoded as a score of -inf (rows are reset before every walk) and "no
+// value yet" as an accumulator of -inf, so one comparison `cand > acc` is the whole
+// relaxation rule of model.rs:100-101 — empty targets take the first finite candidate,
+// later ones only when strictly greater, absent tokens and unreachable sources give
+// cand = -inf and never win.  This needs every vocabulary score to be finite; models
+// with +-inf / NaN scores use the generic kernel instead.
+constexpr uint32_t kNoHandle = 0xFFFFFFFFu;
+
 template <int U>
-__device__ __forceinline__ void relax4_step(const double* scr, const uint32_t* hlr, uint32_t lbit, uint32_t m_rot,
-                                            double& acc, uint32_t& bpv, uint32_t& fin, uint64_t& reach,
-                                            uint64_t& reached) {
-    constexpr uint64_t MU = kRowLane0 << U;          // lanes with l == U
-    fin = sel_u32(MU, bpv, fin);                     // back-pointer of position p0 + U is final now
-    reached |= reach & MU;                           // ... and so is whether it can be reached at all
-    const uint32_t m_eff = sel_u32(reach, m_rot, 0u);  // unreachable positions push nothing (model.rs:85-87)
-    const uint32_t mi = row_bcast_u32<0x150 + U>(m_eff);
+__device__ __forceinline__ void relax4_step(double sv, uint32_t hv, double& acc, uint32_t& bpv, uint32_t& fin) {
+    constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
+    const double ninf = -__builtin_huge_val();
+    fin = sel_u32(MU, bpv, fin);             // back-pointer of position p0 + U is final now
     const double best = row_bcast_f64<U>(acc);
-    const uint64_t active = __builtin_amdgcn_ballot_w64((mi & lbit) != 0u);
-    const double sv = scr[U * 16];
-    const uint32_t hv = hlr[U * 16];
-    const double cand = best + sv;  // model.rs:98
-    const uint64_t gt = __builtin_amdgcn_ballot_w64(cand > acc);
-    reach &= ~MU;  // lane U of each row now accumulates position p0 + U + 16
-    const uint64_t take = active & (~reach | gt);  // model.rs:101: empty, or strict '>'
-    acc = sel_f64(take, cand, acc);
-    bpv = sel_u32(take, hv, bpv);
-    reach |= active;
+    acc = sel_f64(MU, ninf, acc);            // lane U of each row now accumulates position p0 + U + 16
+    bpv = sel_u32(MU, kNoHandle, bpv);
+    const double cand = best + sv;           // model.rs:98
+    const bool take = cand > acc;            // model.rs:101
+    acc = take ? cand : acc;
+    bpv = take ? hv : bpv;
 }
 
 // rows4 LDS: 1024 (score, handle) entries per wave and 16-position group, and — shared
@@ -371,7 +372,19 @@ constexpr uint32_t kRows4GroupBytes = kRows4Entries * 12u;  // 12288
 
 // PPL = positions per lane and iteration: a row advances 16*PPL positions per trip of
 // the dependent gather chain.
-template <bool DROPOUT, int PPL>
+// STAMP = true is a diagnostic build only (TGX_STAMPS=1): s_memtime stamps around the phases
+// of an iteration, summed per wave into P.stamps; its run time is not representative.
+#define TGX_STAMP(i)                                                   \
+    if (STAMP) {                                                       \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        const uint64_t _now = (uint64_t)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                            \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        seg[i] += _now - t_last;                                       \
+        t_last = _now;                                                 \
+    }
+
+template <bool DROPOUT, int PPL, bool STAMP>
 __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
@@ -394,12 +407,15 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     uint32_t s = 0, n = 0, p0 = 0;
     uint64_t beg = 0;
     bool live = false, need_new = true;
-    double acc = 0.0;
-    uint32_t bpv = 0;
-    uint64_t reach = 0;  // wave-uniform: bit = lane holds a value
-
-    const uint32_t lbit = 1u << l;
-    const uint32_t rot = (l + 1u) & 15u;
+    const double ninf = -__builtin_huge_val();
+    double acc = ninf;            // best[e] of the end position this lane accumulates; -inf = none yet
+    uint32_t bpv = kNoHandle;     // its back-pointer: slot << 6 | (len - 1)
+    uint32_t wn[4 * PPL + 1];  // prefetched text window of the next block
+#pragma unroll
+    for (int q = 0; q <= 4 * PPL; ++q) wn[q] = 0;
+    uint64_t seg[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t t_last = STAMP ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
+    uint32_t iters = 0;
 
     for (;;) {
         // ---- rows that finished their sample take the next one
@@ -412,27 +428,44 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
                 k += n_rows;
             }
             p0 = 0;
-            acc = 0.0;
-            bpv = 0;
+            acc = (l == 0u) ? 0.0 : ninf;  // position 0: score 0, reachable
+            bpv = kNoHandle;
         }
-        const uint64_t fresh = __builtin_amdgcn_ballot_w64(need_new);
-        reach = (reach & ~fresh) | (fresh & kRowLane0);  // position 0: score 0, reachable
+        const bool fresh_row = need_new;
         need_new = false;
         if (__builtin_amdgcn_ballot_w64(live) == 0) break;  // every row ran out of samples
+        iters++;
+        TGX_STAMP(0)  // sample switching
 
-        // ---- match: 64*PPL trie walks; lane (r, l) owns positions p0 + 16*g + l, g < PPL
+        // ---- match: 64*PPL trie walks; lane (r, l) owns positions p0 + 16*g + l, g < PPL.
+        // The text window of a row's NEXT block was requested one iteration ago (wn); only
+        // rows that just switched samples load theirs now.
         const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p0 + l : 0));
         const uint32_t sh = (uint32_t)(addr & 3u);
         const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
         uint32_t w[4 * PPL + 1];
+        if (fresh_row) {
 #pragma unroll
-        for (int q = 0; q <= 4 * PPL; ++q) w[q] = wp[q];
+            for (int q = 0; q <= 4 * PPL; ++q) w[q] = wp[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q <= 4 * PPL; ++q) w[q] = wn[q];
+        }
         uint32_t bytes[PPL][4];
 #pragma unroll
         for (int g = 0; g < PPL; ++g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) bytes[g][q] = __builtin_amdgcn_alignbyte(w[4 * g + q + 1], w[4 * g + q], sh);
 
+        TGX_STAMP(1)  // text window
+        // every (row, len) starts as "no token"
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            // the wave sweeps its 8 KiB of scores linearly (1 KiB per instruction, conflict-free)
+            double2* grp = reinterpret_cast<double2*>(wbase + g * kRows4GroupBytes);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) grp[q * 64 + lane] = make_double2(ninf, ninf);
+        }
         uint32_t pg[PPL], maxd[PPL], cur[PPL], base[PPL], m[PPL];
         bool alive[PPL];
 #pragma unroll
@@ -496,38 +529,50 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
             }
         }
         __builtin_amdgcn_wave_barrier();
+        TGX_STAMP(2)  // trie walk
+        {   // request the following block's text window now (vector loads return in order, so
+            // this must come after the walk's last gather): it lands while the relax runs
+            const uint32_t* __restrict__ np = wp + 4 * PPL;  // + SPAN bytes, same alignment
+#pragma unroll
+            for (int q = 0; q <= 4 * PPL; ++q) wn[q] = np[q];
+        }
 
-        // ---- relax: 16*PPL static steps, four positions (one per row) per step
+        // ---- relax: 16*PPL static steps, four positions (one per row) per step.  All 16 LDS
+        // reads of a group are issued before the dependent chain starts.
         uint32_t fin[PPL];
-        uint64_t reached[PPL];
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
-            fin[g] = 0;
-            reached[g] = 0;  // bit = that lane's position was reachable when it was finalised
+            fin[g] = kNoHandle;
             if (P.flags & 2u) continue;
             // row (r*16 + U), column (l - 1) & 15: see relax4_step
             const double* scr = reinterpret_cast<const double*>(wbase + g * kRows4GroupBytes) + r * 256u + ((l - 1u) & 15u);
             const uint32_t* hlr = reinterpret_cast<const uint32_t*>(wbase + g * kRows4GroupBytes + kRows4Entries * 8u) + r * 256u + ((l - 1u) & 15u);
-            // bit t of m_rot <-> target lane t of the row: token length L pushes into lane (l + L) & 15
-            const uint32_t m_rot = ((m[g] << rot) | (m[g] >> (16u - rot))) & 0xFFFFu;
-            relax4_step<0>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<1>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<2>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<3>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<4>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<5>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<6>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<7>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<8>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<9>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<10>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<11>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<12>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<13>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<14>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
-            relax4_step<15>(scr, hlr, lbit, m_rot, acc, bpv, fin[g], reach, reached[g]);
+            double sv[16];
+            uint32_t hv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                sv[u] = scr[u * 16];
+                hv[u] = hlr[u * 16];
+            }
+            relax4_step<0>(sv[0], hv[0], acc, bpv, fin[g]);
+            relax4_step<1>(sv[1], hv[1], acc, bpv, fin[g]);
+            relax4_step<2>(sv[2], hv[2], acc, bpv, fin[g]);
+            relax4_step<3>(sv[3], hv[3], acc, bpv, fin[g]);
+            relax4_step<4>(sv[4], hv[4], acc, bpv, fin[g]);
+            relax4_step<5>(sv[5], hv[5], acc, bpv, fin[g]);
+            relax4_step<6>(sv[6], hv[6], acc, bpv, fin[g]);
+            relax4_step<7>(sv[7], hv[7], acc, bpv, fin[g]);
+            relax4_step<8>(sv[8], hv[8], acc, bpv, fin[g]);
+            relax4_step<9>(sv[9], hv[9], acc, bpv, fin[g]);
+            relax4_step<10>(sv[10], hv[10], acc, bpv, fin[g]);
+            relax4_step<11>(sv[11], hv[11], acc, bpv, fin[g]);
+            relax4_step<12>(sv[12], hv[12], acc, bpv, fin[g]);
+            relax4_step<13>(sv[13], hv[13], acc, bpv, fin[g]);
+            relax4_step<14>(sv[14], hv[14], acc, bpv, fin[g]);
+            relax4_step<15>(sv[15], hv[15], acc, bpv, fin[g]);
         }
         __builtin_amdgcn_wave_barrier();
+        TGX_STAMP(3)  // relax
 
         // ---- back-pointers of the SPAN positions (streamed past the caches), next block
 #pragma unroll
@@ -538,12 +583,18 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
             if (left < SPAN) {  // position n lies in this iteration: the sample is done
 #pragma unroll
                 for (int g = 0; g < PPL; ++g)
-                    if (left == 16u * g + l) P.status[s] = (uint32_t)((reached[g] >> lane) & 1ULL);
+                    if (left == 16u * g + l) P.status[s] = (n == 0u || fin[g] != kNoHandle) ? 1u : 0u;
                 need_new = true;
             } else {
                 p0 += SPAN;
             }
         }
+        TGX_STAMP(4)  // stores, bookkeeping
+    }
+    if (STAMP && lane == 0 && P.stamps) {
+        unsigned long long* o = P.stamps + (size_t)(blockIdx.x * wpb + wave) * 8u;
+        for (int i = 0; i < 5; ++i) o[i] = seg[i];
+        o[5] = iters;
     }
 }
 
@@ -660,10 +711,11 @@ hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out) {
 
 // four-samples-per-wave path (max token length <= 16): one block per CU
 typedef void (*encode4_fn)(EncodeParams);
-static encode4_fn pick_encode4(bool dropout, int ppl) {
-    if (ppl == 1) return dropout ? encode4_kernel<true, 1> : encode4_kernel<false, 1>;
-    if (ppl == 2) return dropout ? encode4_kernel<true, 2> : encode4_kernel<false, 2>;
-    return dropout ? encode4_kernel<true, 4> : encode4_kernel<false, 4>;
+static encode4_fn pick_encode4(bool dropout, int ppl, bool stamp = false) {
+    if (stamp) return encode4_kernel<false, 1, true>;
+    if (ppl == 1) return dropout ? encode4_kernel<true, 1, false> : encode4_kernel<false, 1, false>;
+    if (ppl == 2) return dropout ? encode4_kernel<true, 2, false> : encode4_kernel<false, 2, false>;
+    return dropout ? encode4_kernel<true, 4, false> : encode4_kernel<false, 4, false>;
 }
 // LDS split: `bpc` blocks per CU share its 160 KiB; what a block's waves do not need for
 // their match groups caches the leading trie slots (whole 256-slot XOR blocks).
@@ -682,6 +734,12 @@ hipError_t encode4_prepare(bool dropout, int ppl) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
+    if (p.stamps) {
+        encode4_fn fn = pick_encode4(false, 1, true);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), encode4_lds_bytes(waves, 1, p.cache_slots), stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(pick_encode4(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * (uint32_t)waves),
                        encode4_lds_bytes(waves, ppl, p.cache_slots), stream, p);
     return hipGetLastError();

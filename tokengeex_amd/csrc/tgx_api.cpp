@@ -109,6 +109,7 @@ struct tgx_model {
     int device = 0;
     uint32_t vocab_size = 0;
     uint32_t lm = 0;  // max token length rounded up to a multiple of 4 (>= 4)
+    bool scores_finite = true;  // the four-samples-per-wave kernel encodes 'no token' as -inf
     tgx::FlatTrie flat;
     void* d_trie = nullptr;
     uint32_t* d_tokid = nullptr;
@@ -247,7 +248,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     }
     // TGX_PATH=fused forces the one-sample-per-wave kernel (A/B timing, tests of both paths)
     const char* force = getenv("TGX_PATH");
-    const bool use4 = m->lm <= 16 && !(force && strcmp(force, "fused") == 0);
+    const bool use4 = m->lm <= 16 && m->scores_finite && !(force && strcmp(force, "fused") == 0);
     if (debug_on())
         fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u\n",
                 (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? "rows4" : "fused",
@@ -273,9 +274,32 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
             1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
+        unsigned long long* d_stamps = nullptr;
+        const size_t n_stamp_waves = (size_t)blocks4 * (size_t)waves;
+        if (const char* e = getenv("TGX_STAMPS")) {
+            if (*e == '1' && dropout <= 0.0 && ppl == 1) {
+                HIP_TRY(hipMalloc((void**)&d_stamps, n_stamp_waves * 64));
+                HIP_TRY(hipMemsetAsync(d_stamps, 0, n_stamp_waves * 64, m->stream));
+                p.stamps = d_stamps;
+            }
+        }
         time_begin(m, "encode4_kernel");
         HIP_TRY(tgx::launch_encode4(p, ppl, waves, blocks4, m->stream));
         time_end(m);
+        if (d_stamps) {  // diagnostic: mean cycles per iteration and phase over all waves
+            std::vector<unsigned long long> h(n_stamp_waves * 8);
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            HIP_TRY(hipMemcpy(h.data(), d_stamps, n_stamp_waves * 64, hipMemcpyDeviceToHost));
+            double sum[5] = {0, 0, 0, 0, 0}, iters = 0;
+            for (size_t w = 0; w < n_stamp_waves; w++) {
+                for (int i = 0; i < 5; i++) sum[i] += (double)h[w * 8 + i];
+                iters += (double)h[w * 8 + 5];
+            }
+            fprintf(stderr, "[tgx] stamps (s_memtime ticks per wave-iteration, %zu waves, %.0f iterations): switch %.0f  text %.0f  walk %.0f  relax %.0f  store %.0f\n",
+                    n_stamp_waves, iters, sum[0] / iters, sum[1] / iters, sum[2] / iters, sum[3] / iters, sum[4] / iters);
+            (void)hipFree(d_stamps);
+            p.stamps = nullptr;
+        }
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
         time_begin(m, mode == tgx::MODE_ENCODE ? "trace_kernel" : "trace_count_kernel");
@@ -351,6 +375,8 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
         m->vocab_offs.resize(vocab_size + 1);
         for (uint32_t i = 0; i <= vocab_size; i++) m->vocab_offs[i] = offs[i] - offs[0];
         m->vocab_scores.assign(scores, scores + vocab_size);
+        for (uint32_t i = 0; i < vocab_size; i++)
+            if (!(scores[i] - scores[i] == 0.0)) m->scores_finite = false;  // inf or NaN
     } else {
         m->vocab_offs.assign(1, 0);
     }
