@@ -22,6 +22,9 @@ struct EncodeParams {
     uint32_t* tmp;                  // u32[N] right-aligned ids per sample (MODE_ENCODE)
     uint32_t* counts;               // u32[S] tokens per sample
     uint32_t* status;               // u32[S] 1 = end of sample reachable (encode4 -> trace)
+    uint8_t* bp8;                   // u8[N] rows4 back-pointers: len - 1, 0xFF = unreachable
+    const void* tokhash;            // TokHashEntry[mask + 1]: token bytes -> id (rows4 trace)
+    uint32_t tokhash_mask;
     unsigned long long* freq;       // u64[V] histogram (MODE_COUNT)
     unsigned long long* next;       // work counter (zeroed before launch)
     unsigned long long* err_sample; // min failing sample (init ~0)
@@ -86,6 +89,7 @@ uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out);
 hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
 uint32_t encode4_cache_slots(int waves, int ppl, int bpc, uint32_t n_slots);
+uint32_t encode4_group_bytes();
 uint32_t encode4_lds_bytes(int waves, int ppl, uint32_t cache_slots);
 hipError_t encode4_prepare(bool dropout, int ppl);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream);

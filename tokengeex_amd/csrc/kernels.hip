@@ -347,28 +347,32 @@ constexpr uint64_t kRowLane0 = 0x0001000100010001ULL;  // lane 0 of each 16-lane
 // later ones only when strictly greater, absent tokens and unreachable sources give
 // cand = -inf and never win.  This needs every vocabulary score to be finite; models
 // with +-inf / NaN scores use the generic kernel instead.
-constexpr uint32_t kNoHandle = 0xFFFFFFFFu;
+constexpr uint32_t kNoStep = 0xFFu;  // "nothing pushed into this accumulator yet"
 
+// The winner is remembered as the step U that pushed it; with the lane's own index that
+// gives the token length ((l - U - 1) & 15) + 1, the only thing the trace needs: the
+// token id is looked up from the token's bytes (hash table), so no trie handle travels
+// through LDS and the match buffer is 8 bytes per (position, length).
 template <int U>
-__device__ __forceinline__ void relax4_step(double sv, uint32_t hv, double& acc, uint32_t& bpv, uint32_t& fin) {
+__device__ __forceinline__ void relax4_step(double sv, double& acc, uint32_t& bpv, uint32_t& fin) {
     constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
     const double ninf = -__builtin_huge_val();
-    fin = sel_u32(MU, bpv, fin);             // back-pointer of position p0 + U is final now
+    fin = sel_u32(MU, bpv, fin);             // winner step of position p0 + U is final now
     const double best = row_bcast_f64<U>(acc);
     acc = sel_f64(MU, ninf, acc);            // lane U of each row now accumulates position p0 + U + 16
-    bpv = sel_u32(MU, kNoHandle, bpv);
+    bpv = sel_u32(MU, kNoStep, bpv);
     const double cand = best + sv;           // model.rs:98
     const bool take = cand > acc;            // model.rs:101
     acc = take ? cand : acc;
-    bpv = take ? hv : bpv;
+    bpv = take ? (uint32_t)U : bpv;
 }
 
-// rows4 LDS: 1024 (score, handle) entries per wave and 16-position group, and — shared
+// rows4 LDS: 1024 f64 scores per wave and 16-position group, and — shared
 // by all waves of the block — the first P.cache_slots records of the trie.  With the
 // hottest-first slot order those take ~80 % of all trie gathers at 4096 slots (64 KiB),
 // which would otherwise queue in the CU's vector L1.  One block per CU.
 constexpr uint32_t kRows4Entries = 1024;
-constexpr uint32_t kRows4GroupBytes = kRows4Entries * 12u;  // 12288
+constexpr uint32_t kRows4GroupBytes = kRows4Entries * 8u;  // 8192
 
 // PPL = positions per lane and iteration: a row advances 16*PPL positions per trip of
 // the dependent gather chain.
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     bool live = false, need_new = true;
     const double ninf = -__builtin_huge_val();
     double acc = ninf;            // best[e] of the end position this lane accumulates; -inf = none yet
-    uint32_t bpv = kNoHandle;     // its back-pointer: slot << 6 | (len - 1)
+    uint32_t bpv = kNoStep;       // step (source position mod 16) that pushed the current best
     uint32_t wn[4 * PPL + 1];  // prefetched text window of the next block
 #pragma unroll
     for (int q = 0; q <= 4 * PPL; ++q) wn[q] = 0;
@@ -429,7 +433,7 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
             }
             p0 = 0;
             acc = (l == 0u) ? 0.0 : ninf;  // position 0: score 0, reachable
-            bpv = kNoHandle;
+            bpv = kNoStep;
         }
         const bool fresh_row = need_new;
         need_new = false;
@@ -518,11 +522,9 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
                         }
                         if (term) {
                             double* scw = reinterpret_cast<double*>(wbase + g * kRows4GroupBytes) + lane * LM;
-                            uint32_t* hlw = reinterpret_cast<uint32_t*>(wbase + g * kRows4GroupBytes + kRows4Entries * 8u) + lane * LM;
                             const uint32_t col = ((uint32_t)d + l) & 15u;  // (len - 1 + row) & 15
                             m[g] |= 1u << d;
                             scw[col] = __hiloint2double((int)rec[g].w, (int)rec[g].z);
-                            hlw[col] = (t[g] << 6) | (uint32_t)d;
                         }
                     }
                 }
@@ -542,34 +544,29 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
         uint32_t fin[PPL];
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
-            fin[g] = kNoHandle;
+            fin[g] = kNoStep;
             if (P.flags & 2u) continue;
             // row (r*16 + U), column (l - 1) & 15: see relax4_step
             const double* scr = reinterpret_cast<const double*>(wbase + g * kRows4GroupBytes) + r * 256u + ((l - 1u) & 15u);
-            const uint32_t* hlr = reinterpret_cast<const uint32_t*>(wbase + g * kRows4GroupBytes + kRows4Entries * 8u) + r * 256u + ((l - 1u) & 15u);
             double sv[16];
-            uint32_t hv[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                sv[u] = scr[u * 16];
-                hv[u] = hlr[u * 16];
-            }
-            relax4_step<0>(sv[0], hv[0], acc, bpv, fin[g]);
-            relax4_step<1>(sv[1], hv[1], acc, bpv, fin[g]);
-            relax4_step<2>(sv[2], hv[2], acc, bpv, fin[g]);
-            relax4_step<3>(sv[3], hv[3], acc, bpv, fin[g]);
-            relax4_step<4>(sv[4], hv[4], acc, bpv, fin[g]);
-            relax4_step<5>(sv[5], hv[5], acc, bpv, fin[g]);
-            relax4_step<6>(sv[6], hv[6], acc, bpv, fin[g]);
-            relax4_step<7>(sv[7], hv[7], acc, bpv, fin[g]);
-            relax4_step<8>(sv[8], hv[8], acc, bpv, fin[g]);
-            relax4_step<9>(sv[9], hv[9], acc, bpv, fin[g]);
-            relax4_step<10>(sv[10], hv[10], acc, bpv, fin[g]);
-            relax4_step<11>(sv[11], hv[11], acc, bpv, fin[g]);
-            relax4_step<12>(sv[12], hv[12], acc, bpv, fin[g]);
-            relax4_step<13>(sv[13], hv[13], acc, bpv, fin[g]);
-            relax4_step<14>(sv[14], hv[14], acc, bpv, fin[g]);
-            relax4_step<15>(sv[15], hv[15], acc, bpv, fin[g]);
+            for (int u = 0; u < 16; ++u) sv[u] = scr[u * 16];
+            relax4_step<0>(sv[0], acc, bpv, fin[g]);
+            relax4_step<1>(sv[1], acc, bpv, fin[g]);
+            relax4_step<2>(sv[2], acc, bpv, fin[g]);
+            relax4_step<3>(sv[3], acc, bpv, fin[g]);
+            relax4_step<4>(sv[4], acc, bpv, fin[g]);
+            relax4_step<5>(sv[5], acc, bpv, fin[g]);
+            relax4_step<6>(sv[6], acc, bpv, fin[g]);
+            relax4_step<7>(sv[7], acc, bpv, fin[g]);
+            relax4_step<8>(sv[8], acc, bpv, fin[g]);
+            relax4_step<9>(sv[9], acc, bpv, fin[g]);
+            relax4_step<10>(sv[10], acc, bpv, fin[g]);
+            relax4_step<11>(sv[11], acc, bpv, fin[g]);
+            relax4_step<12>(sv[12], acc, bpv, fin[g]);
+            relax4_step<13>(sv[13], acc, bpv, fin[g]);
+            relax4_step<14>(sv[14], acc, bpv, fin[g]);
+            relax4_step<15>(sv[15], acc, bpv, fin[g]);
         }
         __builtin_amdgcn_wave_barrier();
         TGX_STAMP(3)  // relax
@@ -577,13 +574,17 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
         // ---- back-pointers of the SPAN positions (streamed past the caches), next block
 #pragma unroll
         for (int g = 0; g < PPL; ++g)
-            if (live && pg[g] >= 1u && pg[g] <= n) __builtin_nontemporal_store(fin[g], P.bp + beg + pg[g] - 1);
+            if (live && pg[g] >= 1u && pg[g] <= n) {
+                // winner pushed at step U = fin into lane l: token length ((l - U - 1) & 15) + 1
+                const uint8_t b = (fin[g] == kNoStep) ? (uint8_t)0xFF : (uint8_t)((l - fin[g] - 1u) & 15u);
+                __builtin_nontemporal_store(b, P.bp8 + beg + pg[g] - 1);
+            }
         if (live) {
             const uint32_t left = n - p0;
             if (left < SPAN) {  // position n lies in this iteration: the sample is done
 #pragma unroll
                 for (int g = 0; g < PPL; ++g)
-                    if (left == 16u * g + l) P.status[s] = (n == 0u || fin[g] != kNoHandle) ? 1u : 0u;
+                    if (left == 16u * g + l) P.status[s] = (n == 0u || fin[g] != kNoStep) ? 1u : 0u;
                 need_new = true;
             } else {
                 p0 += SPAN;
@@ -598,19 +599,94 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     }
 }
 
-// Back-trace + id emission for samples whose back-pointers are already in HBM.
+// same function as tgx::tok_hash64 (trie_build.h)
+__device__ __forceinline__ uint64_t tok_hash64_dev(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t len) {
+    uint64_t h = (((uint64_t)w1 << 32) | w0) * 0x9E3779B97F4A7C15ULL;
+    h ^= ((((uint64_t)w3 << 32) | w2) + len) * 0xC2B2AE3D27D4EB4FULL;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ULL;
+    h ^= h >> 32;
+    return h;
+}
+
+// Back-trace + id emission for the rows4 path: one wave per sample, 1-byte back-pointers
+// (token length - 1), ids recovered from the token's bytes through the hash table.
 template <int MODE>
 __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t n_waves = gridDim.x * wpb;
     const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+    const uint4* __restrict__ table = reinterpret_cast<const uint4*>(P.tokhash);
     for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
         const uint64_t beg = first_u64(P.offs[s]);
         const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
         const uint32_t reach_n = (n == 0) ? 1u : (uint32_t)__builtin_amdgcn_readfirstlane((int)P.status[s]);
-        trace_sample<MODE>(P, s, beg, n, lane, P.bp + beg, reach_n);
+        const uint8_t* __restrict__ bp = P.bp8 + beg;
+        const uint8_t* __restrict__ text = P.text + beg;
+        uint32_t total = 0;
+        uint64_t cursor = beg + n;  // one past this sample's slice of tmp
+        int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // Error::NoPath(n, n) otherwise (model.rs:119)
+        if (P.flags & 4u) q = -1;
+        while (q >= 0) {
+            const uint32_t wq = (uint32_t)q & ~63u;
+            const uint32_t idx = wq + lane;
+            const uint32_t h = (idx < n) ? (uint32_t)bp[idx] : 0u;
+            uint64_t ends = 0;
+            int32_t qq = (int32_t)((uint32_t)q - wq);
+            while (qq >= 0) {  // model.rs:113-126, 64 positions per load
+                const uint32_t hh = readlane_u32(h, (uint32_t)qq);
+                ends |= 1ULL << qq;
+                qq -= (int32_t)(hh & 15u) + 1;
+            }
+            q = (int64_t)wq + qq;
+            const uint32_t cnt = (uint32_t)__popcll(ends);
+            if ((ends >> lane) & 1ULL) {
+                // token = text[e - len .. e), e = idx + 1
+                const uint32_t len = (h & 15u) + 1u;
+                const uintptr_t addr = reinterpret_cast<uintptr_t>(text + (idx + 1u - len));
+                const uint32_t sh = (uint32_t)(addr & 3u);
+                const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
+                uint32_t w[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) w[j] = wp[j];
+                uint32_t b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
+                    const uint32_t nb = len > 4u * j ? len - 4u * j : 0u;  // bytes of the token in this dword
+                    b[j] = nb >= 4u ? v : (v & ((1u << (8u * nb)) - 1u));
+                }
+                const uint64_t hk = tok_hash64_dev(b[0], b[1], b[2], b[3], len);
+                uint32_t slot = (uint32_t)hk & P.tokhash_mask;
+                uint32_t id = 0;
+                bool found = false;
+                for (uint32_t probe = 0; probe <= P.tokhash_mask && !found; ++probe) {
+                    const uint4 e = table[slot];
+                    if (e.w == 0u) break;  // empty slot: the back-pointer does not name a vocabulary token
+                    if (e.x == (uint32_t)hk && e.y == (uint32_t)(hk >> 32)) {
+                        id = e.z;
+                        found = true;
+                    }
+                    slot = (slot + 1u) & P.tokhash_mask;
+                }
+                // cannot happen unless a kernel bug corrupted a back-pointer: report, do not fault
+                if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
+                if (MODE == MODE_ENCODE) {
+                    const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
+                    P.tmp[cursor - 1 - above] = id;
+                } else {
+                    atomicAdd(&P.freq[id], 1ULL);
+                }
+            }
+            cursor -= cnt;
+            total += cnt;
+        }
+        if (lane == 0) {
+            P.counts[s] = total;
+            if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);
+        }
     }
 }
 
@@ -726,6 +802,7 @@ uint32_t encode4_cache_slots(int waves, int ppl, int bpc, uint32_t n_slots) {
     k &= ~255u;
     return k < n_slots ? k : (n_slots & ~255u);
 }
+uint32_t encode4_group_bytes() { return kRows4GroupBytes; }
 uint32_t encode4_lds_bytes(int waves, int ppl, uint32_t cache_slots) {
     return cache_slots * 16u + (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes;
 }

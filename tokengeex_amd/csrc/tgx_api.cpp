@@ -124,6 +124,8 @@ struct tgx_model {
     std::vector<double> vocab_scores;
     tgx::FlatTrie flat_rev;
     void* d_trie_rev = nullptr;
+    tgx::TokHashTable tokhash;      // token bytes -> id (rows4 trace); ok == false: not usable
+    void* d_tokhash = nullptr;
     int estep_blocks_per_cu = 0;
     KernelTime timed[kMaxTimed] = {};
     int n_timed = 0;
@@ -237,6 +239,9 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     p.tmp = c->d_tmp;
     p.counts = c->d_counts;
     p.status = c->d_status;
+    p.bp8 = reinterpret_cast<uint8_t*>(c->d_bp);  // the rows4 path uses the scratch row as bytes
+    p.tokhash = m->d_tokhash;
+    p.tokhash_mask = m->tokhash.mask;
     p.freq = d_freq;
     p.next = m->d_ctrl;
     p.err_sample = m->d_ctrl + 1;
@@ -248,7 +253,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     }
     // TGX_PATH=fused forces the one-sample-per-wave kernel (A/B timing, tests of both paths)
     const char* force = getenv("TGX_PATH");
-    const bool use4 = m->lm <= 16 && m->scores_finite && !(force && strcmp(force, "fused") == 0);
+    const bool use4 = m->lm <= 16 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
     if (debug_on())
         fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u\n",
                 (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? "rows4" : "fused",
@@ -256,7 +261,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     if (use4) {
         // `bpc` blocks per CU of `waves` waves each; LDS left over caches the hottest trie
         // slots.  TGX_PPL (positions per lane: 1, 2, 4), TGX_WAVES, TGX_BPC override the defaults.
-        int ppl = 1, waves = 4, bpc = 3;
+        int ppl = 1, waves = 4, bpc = 5;
         if (const char* e = getenv("TGX_PPL")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) ppl = v;
@@ -269,7 +274,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
             const int v = atoi(e);
             if (v >= 1 && v <= 8) bpc = v;
         }
-        while (waves > 1 && (uint32_t)(waves * ppl) * 12288u > (160u * 1024u) / (uint32_t)bpc) waves--;
+        while (waves > 1 && (uint32_t)(waves * ppl) * tgx::encode4_group_bytes() > (160u * 1024u) / (uint32_t)bpc) waves--;
         p.cache_slots = tgx::encode4_cache_slots(waves, ppl, bpc, p.n_slots);
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
@@ -401,6 +406,14 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
     HIP_TRY_M(hipMalloc(&m->d_trie, tbytes));
     HIP_TRY_M(hipMalloc((void**)&m->d_tokid, m->flat.tokid.size() * 4));
     HIP_TRY_M(hipMalloc((void**)&m->d_ctrl, 64));
+    if (m->lm <= 16 && m->scores_finite) {
+        tgx::build_tok_hash(bytes, vocab_size ? offs : zero_offs, vocab_size, &m->tokhash);
+        if (m->tokhash.ok) {
+            const size_t hb = m->tokhash.slots.size() * sizeof(tgx::TokHashEntry);
+            HIP_TRY_M(hipMalloc(&m->d_tokhash, hb));
+            HIP_TRY_M(hipMemcpyAsync(m->d_tokhash, m->tokhash.slots.data(), hb, hipMemcpyHostToDevice, m->stream));
+        }
+    }
     HIP_TRY_M(hipHostMalloc((void**)&m->h_ctrl, 64, hipHostMallocDefault));
     HIP_TRY_M(hipMemcpyAsync(m->d_trie, m->flat.table.data(), tbytes, hipMemcpyHostToDevice, m->stream));
     HIP_TRY_M(hipMemcpyAsync(m->d_tokid, m->flat.tokid.data(), m->flat.tokid.size() * 4,
@@ -434,6 +447,7 @@ void tgx_model_destroy(tgx_model* m) {
     }
     if (m->d_trie) (void)hipFree(m->d_trie);
     if (m->d_trie_rev) (void)hipFree(m->d_trie_rev);
+    if (m->d_tokhash) (void)hipFree(m->d_tokhash);
     if (m->d_tokid) (void)hipFree(m->d_tokid);
     if (m->d_ctrl) (void)hipFree(m->d_ctrl);
     if (m->h_ctrl) (void)hipHostFree(m->h_ctrl);

@@ -217,6 +217,45 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     out->n_nodes = n_nodes;
 }
 
+void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out) {
+    uint32_t cap = 1024;
+    while (cap < vocab_size * 2u) cap <<= 1;
+    out->slots.assign(cap, TokHashEntry{0, 0, 0});
+    out->mask = cap - 1;
+    out->ok = true;
+    for (uint32_t id = 0; id < vocab_size; id++) {
+        const uint64_t b = offs[id], e = offs[id + 1];
+        const uint32_t len = (uint32_t)(e - b);
+        if (len == 0) continue;  // never matched
+        if (len > 16) {
+            out->ok = false;
+            return;
+        }
+        uint32_t w[4] = {0, 0, 0, 0};
+        std::memcpy(w, bytes + b, len);
+        const uint64_t h = tok_hash64(w[0], w[1], w[2], w[3], len);
+        uint32_t i = (uint32_t)h & out->mask;
+        for (;;) {
+            TokHashEntry& s = out->slots[i];
+            if (!s.used) {
+                s = TokHashEntry{h, id, 1};
+                break;
+            }
+            if (s.hash == h) {
+                // same hash: must be the same bytes (a duplicate token: the later id wins, trie.rs:19)
+                const uint64_t ob = offs[s.id], oe = offs[s.id + 1];
+                if (oe - ob != e - b || std::memcmp(bytes + ob, bytes + b, len) != 0) {
+                    out->ok = false;  // a genuine 64-bit collision: keep trie handles
+                    return;
+                }
+                s.id = id;
+                break;
+            }
+            i = (i + 1) & out->mask;
+        }
+    }
+}
+
 uint64_t flat_common_prefix_search(const FlatTrie& t, const uint8_t* s, uint64_t n, uint32_t* ids,
                                    uint32_t* lens, uint64_t cap) {
     uint32_t cur = 0, base = t.table[0].base & ~kTerminalBit;

@@ -41,6 +41,32 @@ struct FlatTrie {
 void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                      uint32_t vocab_size, FlatTrie* out);
 
+// Token-bytes -> id hash table (tokens of 1..16 bytes): lets the trace kernel turn a
+// (start, length) pair straight into a token id with one probe instead of carrying a trie
+// handle through the DP.  Open addressing, linear probing, capacity a power of two >= 2V;
+// entry = {hash64 of the bytes, id, used}.  The 64-bit hash is verified to be collision-free
+// over the vocabulary at build time (ok == false otherwise: callers keep trie handles).
+struct TokHashEntry {
+    uint64_t hash;
+    uint32_t id;
+    uint32_t used;
+};
+struct TokHashTable {
+    std::vector<TokHashEntry> slots;
+    uint32_t mask = 0;
+    bool ok = false;
+};
+// hash of a token of len (1..16) bytes given as four little-endian zero-padded dwords
+inline uint64_t tok_hash64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t len) {
+    uint64_t h = (((uint64_t)w1 << 32) | w0) * 0x9E3779B97F4A7C15ULL;
+    h ^= ((((uint64_t)w3 << 32) | w2) + len) * 0xC2B2AE3D27D4EB4FULL;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ULL;
+    h ^= h >> 32;
+    return h;
+}
+void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out);
+
 // Host twin of the device walk (TrieIterator::next, src/trie.rs:51-63).
 uint64_t flat_common_prefix_search(const FlatTrie& t, const uint8_t* s, uint64_t n, uint32_t* ids,
                                    uint32_t* lens, uint64_t cap);
