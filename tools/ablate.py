@@ -10,7 +10,7 @@ toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
 flat, offs = synth.make_corpus(size << 20, "mixed", seed_offset=1000)
 m = tgx.NativeModel(toks, scores); c = tgx.NativeCorpus(flat, offs)
 names = {0: "full"}
-paths = ["rows4:1:3:6", "rows4:1:4:5", "rows4:1:5:4", "rows4:1:4:4", "rows4:1:2:8"]
+paths = ["rows4:1:4:5"]
 for rnd in range(2):
   for path in paths:
     os.environ["TGX_PATH"] = path.split(":")[0]
