@@ -611,13 +611,18 @@ __device__ __forceinline__ uint64_t tok_hash64_dev(uint32_t w0, uint32_t w1, uin
 
 // Back-trace + id emission for the rows4 path: one wave per sample, 1-byte back-pointers
 // (token length - 1), ids recovered from the token's bytes through the hash table.
-template <int MODE>
+template <int MODE, bool STAMP>
 __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wpb = blockDim.x >> 6;
     const uint32_t n_waves = gridDim.x * wpb;
     const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
     const uint4* __restrict__ table = reinterpret_cast<const uint4*>(P.tokhash);
+    __shared__ uint32_t stage_all[4][32];  // per wave: 80 text bytes + alignment slack + 5-dword over-read
+    uint32_t* stage = stage_all[threadIdx.x >> 6];
+    uint64_t seg[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t t_last = STAMP ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
+    uint32_t iters = 0;
     for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
         const uint64_t beg = first_u64(P.offs[s]);
@@ -629,10 +634,25 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
         uint64_t cursor = beg + n;  // one past this sample's slice of tmp
         int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // Error::NoPath(n, n) otherwise (model.rs:119)
         if (P.flags & 4u) q = -1;
+        // Windows are visited top-down and a token is at most 16 bytes, so the next window is
+        // always the one below: its back-pointers and its text span (text[wq-16 .. wq+64), as
+        // aligned dwords, one per lane) are requested one window ahead — both come from HBM.
+        uint32_t h_cur = 0, t_cur = 0;
+        if (q >= 0) {
+            const uint32_t wq0 = (uint32_t)q & ~63u;
+            const uint32_t a0 = wq0 >= 16u ? wq0 - 16u : 0u;
+            const uint32_t* __restrict__ gw = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + a0) & ~uintptr_t(3));
+            h_cur = (wq0 + lane < n) ? (uint32_t)bp[wq0 + lane] : 0u;
+            t_cur = (lane <= 20u) ? gw[lane] : 0u;
+        }
+        TGX_STAMP(0)  // sample setup
         while (q >= 0) {
+            iters++;
             const uint32_t wq = (uint32_t)q & ~63u;
             const uint32_t idx = wq + lane;
-            const uint32_t h = (idx < n) ? (uint32_t)bp[idx] : 0u;
+            const uint32_t h = h_cur;
+            if (lane < 32u) stage[lane] = t_cur;  // lanes 21..31 write zeros
+            TGX_STAMP(1)  // window loads issued / consumed
             uint64_t ends = 0;
             int32_t qq = (int32_t)((uint32_t)q - wq);
             while (qq >= 0) {  // model.rs:113-126, 64 positions per load
@@ -642,12 +662,26 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
             }
             q = (int64_t)wq + qq;
             const uint32_t cnt = (uint32_t)__popcll(ends);
+            __builtin_amdgcn_wave_barrier();
+            TGX_STAMP(2)  // hops
+            // next window's loads: issued here (after this window's back-pointers were consumed,
+            // vector loads return in order) so that they fly during the token phase
+            uint32_t h_next = 0, t_next = 0;
+            if (wq >= 64u) {
+                const uint32_t wn = wq - 64u;
+                const uint32_t an = wn >= 16u ? wn - 16u : 0u;
+                const uint32_t* __restrict__ gwn = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + an) & ~uintptr_t(3));
+                h_next = (uint32_t)bp[wn + lane];
+                t_next = (lane <= 20u) ? gwn[lane] : 0u;
+            }
             if ((ends >> lane) & 1ULL) {
                 // token = text[e - len .. e), e = idx + 1
                 const uint32_t len = (h & 15u) + 1u;
-                const uintptr_t addr = reinterpret_cast<uintptr_t>(text + (idx + 1u - len));
-                const uint32_t sh = (uint32_t)(addr & 3u);
-                const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
+                const uint32_t a0 = wq >= 16u ? wq - 16u : 0u;
+                const uintptr_t gaddr = reinterpret_cast<uintptr_t>(text + a0);
+                const uint32_t boff = (uint32_t)(gaddr & 3u) + (idx + 1u - len - a0);  // byte offset in stage[]
+                const uint32_t sh = boff & 3u;
+                const uint32_t* wp = stage + (boff >> 2);
                 uint32_t w[5];
 #pragma unroll
                 for (int j = 0; j < 5; ++j) w[j] = wp[j];
@@ -675,18 +709,28 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
                 if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
                 if (MODE == MODE_ENCODE) {
                     const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
-                    P.tmp[cursor - 1 - above] = id;
+                    if (!(P.flags & 16u)) P.tmp[cursor - 1 - above] = id;  // flag: timing experiment
+                    else if (id == 0xFFFFFFFFu) P.tmp[0] = id;
                 } else {
                     atomicAdd(&P.freq[id], 1ULL);
                 }
             }
+            TGX_STAMP(3)  // token bytes, hash, table probe, id store
             cursor -= cnt;
             total += cnt;
+            h_cur = h_next;
+            t_cur = t_next;
+            __builtin_amdgcn_wave_barrier();
         }
         if (lane == 0) {
             P.counts[s] = total;
             if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);
         }
+    }
+    if (STAMP && lane == 0 && P.stamps) {
+        unsigned long long* o = P.stamps + (size_t)wave_id * 8u;
+        for (int i = 0; i < 5; ++i) o[i] = seg[i];
+        o[5] = iters;
     }
 }
 
@@ -822,10 +866,12 @@ hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t bl
     return hipGetLastError();
 }
 hipError_t launch_trace(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream) {
-    if (mode == MODE_ENCODE)
-        hipLaunchKernelGGL(trace_kernel<MODE_ENCODE>, dim3(blocks), dim3(256), 0, stream, p);
+    if (p.stamps)
+        hipLaunchKernelGGL((trace_kernel<MODE_ENCODE, true>), dim3(blocks), dim3(256), 0, stream, p);
+    else if (mode == MODE_ENCODE)
+        hipLaunchKernelGGL((trace_kernel<MODE_ENCODE, false>), dim3(blocks), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL(trace_kernel<MODE_COUNT>, dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((trace_kernel<MODE_COUNT, false>), dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

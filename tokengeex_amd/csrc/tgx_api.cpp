@@ -307,9 +307,32 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
         }
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
+        unsigned long long* d_tstamps = nullptr;
+        const size_t n_twaves = (size_t)blocks_t * 4;
+        if (const char* e = getenv("TGX_STAMPS")) {
+            if (*e == '2' && mode == tgx::MODE_ENCODE) {
+                HIP_TRY(hipMalloc((void**)&d_tstamps, n_twaves * 64));
+                HIP_TRY(hipMemsetAsync(d_tstamps, 0, n_twaves * 64, m->stream));
+                p.stamps = d_tstamps;
+            }
+        }
         time_begin(m, mode == tgx::MODE_ENCODE ? "trace_kernel" : "trace_count_kernel");
         HIP_TRY(tgx::launch_trace(p, mode, blocks_t, m->stream));
         time_end(m);
+        if (d_tstamps) {
+            std::vector<unsigned long long> h(n_twaves * 8);
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            HIP_TRY(hipMemcpy(h.data(), d_tstamps, n_twaves * 64, hipMemcpyDeviceToHost));
+            double sum[5] = {0, 0, 0, 0, 0}, iters = 0;
+            for (size_t w = 0; w < n_twaves; w++) {
+                for (int i = 0; i < 5; i++) sum[i] += (double)h[w * 8 + i];
+                iters += (double)h[w * 8 + 5];
+            }
+            fprintf(stderr, "[tgx] trace stamps (ticks per window, %zu waves, %.0f windows): setup %.0f  loads %.0f  hops %.0f  tokens %.0f\n",
+                    n_twaves, iters, sum[0] / iters, sum[1] / iters, sum[2] / iters, sum[3] / iters);
+            (void)hipFree(d_tstamps);
+            p.stamps = nullptr;
+        }
     } else {
         time_begin(m, mode == tgx::MODE_ENCODE ? "encode_kernel" : "encode_count_kernel");
         HIP_TRY(tgx::launch_encode(p, mode, grid_blocks(m, mode, c->n_samples), m->stream));

@@ -219,7 +219,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
 
 void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out) {
     uint32_t cap = 1024;
-    while (cap < vocab_size * 2u) cap <<= 1;
+    while (cap < vocab_size * 8u) cap <<= 1;  // load factor <= 1/8: a probe chain is as long as its slowest lane
     out->slots.assign(cap, TokHashEntry{0, 0, 0});
     out->mask = cap - 1;
     out->ok = true;

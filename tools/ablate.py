@@ -9,7 +9,7 @@ vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
 toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
 flat, offs = synth.make_corpus(size << 20, "mixed", seed_offset=1000)
 m = tgx.NativeModel(toks, scores); c = tgx.NativeCorpus(flat, offs)
-names = {0: "full"}
+names = {0: "full", 16: "trace without id stores (timing only)"}
 paths = ["rows4:1:4:5"]
 for rnd in range(2):
   for path in paths:

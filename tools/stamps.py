@@ -1,7 +1,7 @@
 """Diagnostic: per-phase s_memtime stamps of the rows4 encode kernel (TGX_STAMPS=1)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["TGX_STAMPS"] = "1"
+os.environ.setdefault("TGX_STAMPS", "1")
 import tokengeex_amd as tgx
 from tokengeex_amd import synth
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
