@@ -16,7 +16,7 @@ struct EncodeParams {
     const uint32_t* tokid;          // u32[n_slots]
     uint32_t root_base;
     uint32_t n_slots;               // trie slots (guards the handle -> id lookup)
-    uint32_t cache_slots;           // rows4: leading trie slots staged in LDS
+    uint32_t cache_slots;           // unused (kept 0): an LDS copy of the hottest slots lost against more waves
     uint32_t lm;                    // max token length rounded up (<= 64)
     uint32_t* bp;                   // u32[N] back-pointer scratch
     uint32_t* tmp;                  // u32[N] right-aligned ids per sample (MODE_ENCODE)
@@ -88,7 +88,6 @@ uint32_t encode_lds_bytes_per_block(uint32_t lm);
 uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out);
 hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
-uint32_t encode4_cache_slots(int waves, int ppl, int bpc, uint32_t n_slots);
 uint32_t encode4_group_bytes();
 uint32_t encode4_lds_bytes(int waves, int ppl, uint32_t cache_slots);
 hipError_t encode4_prepare(bool dropout, int ppl);

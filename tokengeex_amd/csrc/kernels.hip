@@ -367,10 +367,7 @@ __device__ __forceinline__ void relax4_step(double sv, double& acc, uint32_t& bp
     bpv = take ? (uint32_t)U : bpv;
 }
 
-// rows4 LDS: 1024 f64 scores per wave and 16-position group, and — shared
-// by all waves of the block — the first P.cache_slots records of the trie.  With the
-// hottest-first slot order those take ~80 % of all trie gathers at 4096 slots (64 KiB),
-// which would otherwise queue in the CU's vector L1.  One block per CU.
+// rows4 LDS: 1024 f64 scores (8 KiB) per wave and 16-position group — 20 waves per CU.
 constexpr uint32_t kRows4Entries = 1024;
 constexpr uint32_t kRows4GroupBytes = kRows4Entries * 8u;  // 8192
 
@@ -397,11 +394,10 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
-    const uint32_t K = P.cache_slots;
-    uint4* tcache = reinterpret_cast<uint4*>(smem);
-    for (uint32_t i = threadIdx.x; i < K; i += blockDim.x) tcache[i] = trie[i];
-    __syncthreads();
-    unsigned char* wbase = smem + (size_t)K * 16u + (size_t)wave * (PPL * kRows4GroupBytes);
+    // (An LDS copy of the hottest trie slots was tried — 81 % of the gathers hit 64 KiB of
+    // hottest-first slots — and lost: a walk step waits for its slowest lane, which still goes
+    // to L2, while the cache costs waves.  All of the CU's LDS goes to match buffers.)
+    unsigned char* wbase = smem + (size_t)wave * (PPL * kRows4GroupBytes);
 
     const uint32_t wpb = blockDim.x >> 6;
     const uint64_t n_rows = (uint64_t)gridDim.x * wpb * 4u;
@@ -503,10 +499,7 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
                 for (int g = 0; g < PPL; ++g) {
                     const uint32_t c = (bytes[g][d >> 2] >> ((d & 3) * 8)) & 0xFFu;
                     t[g] = alive[g] ? (base[g] ^ c) : 0u;
-                    if (t[g] < K)
-                        rec[g] = tcache[t[g]];
-                    else
-                        rec[g] = trie[t[g]];
+                    rec[g] = trie[t[g]];
                 }
 #pragma unroll
                 for (int g = 0; g < PPL; ++g) asm volatile("" : "+v"(rec[g].x), "+v"(rec[g].y), "+v"(rec[g].z), "+v"(rec[g].w));
@@ -836,15 +829,6 @@ static encode4_fn pick_encode4(bool dropout, int ppl, bool stamp = false) {
     if (ppl == 1) return dropout ? encode4_kernel<true, 1, false> : encode4_kernel<false, 1, false>;
     if (ppl == 2) return dropout ? encode4_kernel<true, 2, false> : encode4_kernel<false, 2, false>;
     return dropout ? encode4_kernel<true, 4, false> : encode4_kernel<false, 4, false>;
-}
-// LDS split: `bpc` blocks per CU share its 160 KiB; what a block's waves do not need for
-// their match groups caches the leading trie slots (whole 256-slot XOR blocks).
-uint32_t encode4_cache_slots(int waves, int ppl, int bpc, uint32_t n_slots) {
-    const uint32_t total = (160u * 1024u) / (uint32_t)bpc;
-    const uint32_t groups = (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes;
-    uint32_t k = groups < total ? (total - groups) / 16u : 0u;
-    k &= ~255u;
-    return k < n_slots ? k : (n_slots & ~255u);
 }
 uint32_t encode4_group_bytes() { return kRows4GroupBytes; }
 uint32_t encode4_lds_bytes(int waves, int ppl, uint32_t cache_slots) {

@@ -259,8 +259,8 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
                 (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? "rows4" : "fused",
                 m->flat.table.size(), p.root_base);
     if (use4) {
-        // `bpc` blocks per CU of `waves` waves each; LDS left over caches the hottest trie
-        // slots.  TGX_PPL (positions per lane: 1, 2, 4), TGX_WAVES, TGX_BPC override the defaults.
+        // `bpc` blocks per CU of `waves` waves each (8 KiB of LDS per wave and position group).
+        // TGX_PPL (positions per lane: 1, 2, 4), TGX_WAVES, TGX_BPC override the defaults.
         int ppl = 1, waves = 4, bpc = 5;
         if (const char* e = getenv("TGX_PPL")) {
             const int v = atoi(e);
@@ -275,7 +275,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
             if (v >= 1 && v <= 8) bpc = v;
         }
         while (waves > 1 && (uint32_t)(waves * ppl) * tgx::encode4_group_bytes() > (160u * 1024u) / (uint32_t)bpc) waves--;
-        p.cache_slots = tgx::encode4_cache_slots(waves, ppl, bpc, p.n_slots);
+        p.cache_slots = 0;  // the LDS trie cache lost against more waves (see kernels.hip)
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
             1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));

@@ -9,8 +9,8 @@ vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
 toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
 flat, offs = synth.make_corpus(size << 20, "mixed", seed_offset=1000)
 m = tgx.NativeModel(toks, scores); c = tgx.NativeCorpus(flat, offs)
-names = {0: "full", 16: "trace without id stores (timing only)"}
-paths = ["rows4:1:4:5"]
+names = {0: "full"}
+paths = ["rows4:1:4:5", "rows4:1:5:4", "rows4:1:2:8"]
 for rnd in range(2):
   for path in paths:
     os.environ["TGX_PATH"] = path.split(":")[0]
