@@ -80,7 +80,7 @@ def test_estep_realistic_corpus():
     # every byte of the corpus is covered with total mass 1
     mass = float(sum(got[i] * len(toks[i]) for i in range(len(toks))))
     assert abs(mass - flat.size) < 1e-6 * flat.size
-    assert "estep_kernel" in nat.last_kernel_times()
+    assert any(k.startswith("estep") for k in nat.last_kernel_times())
 
 
 def test_estep_snippets_long_samples_and_token_lengths():
@@ -133,3 +133,18 @@ def test_count_pairs_small_and_empty():
     flat, offs = tgx.pack([b"", b"c"])
     keys, counts = nat.count_pairs(tgx.NativeCorpus(flat, offs))
     assert keys.size == 0 and counts.size == 0
+
+
+def test_estep_both_kernel_paths_agree(monkeypatch):
+    """Four-snippets-per-wave E-step (estep4.hip) against the generic kernel (TGX_PATH=fused)."""
+    flat, offs, toks, scores = corpus_and_vocab(1 << 20, "mixed", 5000, 16, seed_offset=9)
+    nat, ora = _pair(toks, scores)
+    corpus = tgx.NativeCorpus(flat, offs)
+    monkeypatch.setenv("TGX_PATH", "rows4")
+    a, za = nat.estep(corpus, 20000, 0.05, 3)
+    assert "estep4_fwd_kernel" in nat.last_kernel_times()
+    monkeypatch.setenv("TGX_PATH", "fused")
+    b, zb = nat.estep(corpus, 20000, 0.05, 3)
+    assert "estep_kernel" in nat.last_kernel_times()
+    np.testing.assert_allclose(a, b, rtol=rtol_for(20000), atol=ATOL)
+    assert abs(za - zb) <= 1e-12 * abs(zb)

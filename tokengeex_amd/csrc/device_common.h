@@ -63,6 +63,21 @@ __device__ __forceinline__ double sel_f64(uint64_t mask, double t, double f) {
 }
 
 
+// ---- 16-lane rows (four samples per wave) ----------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t row_bcast_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int U>
+__device__ __forceinline__ double row_bcast_f64(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = row_bcast_u32<0x150 + U>((uint32_t)b);
+    const uint32_t hi = row_bcast_u32<0x150 + U>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+constexpr uint64_t kRowLane0 = 0x0001000100010001ULL;  // lane 0 of each 16-lane row
+
 // One 16-byte trie record in ONE load: the empty asm makes all four words live at
 // once (otherwise the compiler splits the load into three dependent round trips).
 __device__ __forceinline__ uint4 load_rec(const uint4* __restrict__ trie, uint32_t t) {

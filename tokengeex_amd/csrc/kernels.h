@@ -79,6 +79,32 @@ hipError_t ids_rle_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t ids_rle(void* temp, size_t temp_bytes, const uint32_t* sorted, uint64_t n, uint32_t* unique_out,
                    unsigned int* counts_out, unsigned int* n_runs_out, hipStream_t stream);
 
+// four-snippets-per-wave E-step (estep4.hip): the work list is the list of snippets
+struct Estep4Params {
+    const uint8_t* text;            // 256-byte front pad: the backward sweep reads 16 bytes before a position
+    const uint64_t* soffs;          // u64[K+1] snippet k = text[soffs[k] .. soffs[k+1])
+    const uint32_t* order;          // u32[K] longest first
+    uint64_t n_snips;
+    const uint32_t* snip_sample;    // u32[K] sample of the snippet        (dropout hash only)
+    const uint64_t* snip_base;      // u64[K] its byte offset in the sample (dropout hash only)
+    const void* trie_fwd;
+    const void* trie_rev;
+    uint32_t root_fwd, root_rev;
+    double* alpha;                  // f64[N + K + pad]: snippet k's A[0..n] at soffs[k] + k
+    double* zarr;                   // f64[K] z = A[n] per snippet
+    double* expected_slot;          // f64[n_replicas][n_slots_rev]
+    uint32_t n_slots_rev, n_replicas;
+    double* logz_sum;
+    unsigned long long* err_snip;   // min snippet whose z is not normal (init ~0)
+    double dropout;
+    uint64_t seed;
+};
+hipError_t estep4_prepare();
+hipError_t launch_estep4_fwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
+hipError_t launch_estep4_bwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
+hipError_t launch_estep4_reduce(const double* rep, double* out, uint32_t n_slots, uint32_t n_replicas,
+                                hipStream_t stream);
+
 uint32_t estep_lds_bytes_per_block(uint32_t lm);
 uint32_t estep_waves_per_block(uint32_t lm);
 hipError_t estep_max_blocks_per_cu(uint32_t lm, int* out);

@@ -321,19 +321,6 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
 // token of length L pushes into lane (u + L) mod 16.  Same candidate order and strict
 // '>' as block_generic, hence the same bits.  Back-pointers and the per-sample
 // "end reachable" flag go to HBM; trace_kernel turns them into ids.
-template <int CTRL>
-__device__ __forceinline__ uint32_t row_bcast_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
-}
-template <int U>
-__device__ __forceinline__ double row_bcast_f64(double v) {
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = row_bcast_u32<0x150 + U>((uint32_t)b);
-    const uint32_t hi = row_bcast_u32<0x150 + U>((uint32_t)(b >> 32));
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-
-constexpr uint64_t kRowLane0 = 0x0001000100010001ULL;  // lane 0 of each 16-lane row
 
 // LDS layout of a 16-position group (rows4): entry (row, len - 1) lives at column
 // (len - 1 + row) & 15 of its row (row = lane that matched it).  The target lane

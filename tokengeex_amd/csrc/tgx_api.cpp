@@ -137,7 +137,8 @@ struct tgx_corpus {
     int device = 0;
     uint64_t n_samples = 0, n_bytes = 0;
     std::vector<uint64_t> h_offs;
-    uint8_t* d_text = nullptr;
+    uint8_t* d_text = nullptr;        // = d_text_alloc + 256 (the backward E-step sweep reads before a position)
+    uint8_t* d_text_alloc = nullptr;
     uint64_t* d_offs = nullptr;
     uint32_t* d_order = nullptr;
     uint32_t* d_bp = nullptr;      // scratch, allocated on first pass
@@ -580,7 +581,9 @@ tgx_status tgx_corpus_upload(int device, const uint8_t* text, const uint64_t* of
                                 hipGetErrorString(_e), __FILE__, __LINE__, #expr));         \
     } while (0)
     HIP_TRY_C(hipSetDevice(device));
-    HIP_TRY_C(pool_alloc(device, (size_t)c->n_bytes + 256, (void**)&c->d_text));
+    HIP_TRY_C(pool_alloc(device, (size_t)c->n_bytes + 512, (void**)&c->d_text_alloc));
+    c->d_text = c->d_text_alloc + 256;
+    HIP_TRY_C(hipMemset(c->d_text_alloc, 0, 256));
     HIP_TRY_C(pool_alloc(device, (size_t)(n_samples + 1) * 8, (void**)&c->d_offs));
     HIP_TRY_C(pool_alloc(device, (size_t)n_samples * 4 + 4, (void**)&c->d_order));
     if (c->n_bytes) HIP_TRY_C(hipMemcpy(c->d_text, text + base, c->n_bytes, hipMemcpyHostToDevice));
@@ -594,7 +597,7 @@ tgx_status tgx_corpus_upload(int device, const uint8_t* text, const uint64_t* of
 
 void tgx_corpus_free(tgx_corpus* c) {
     if (!c) return;
-    pool_free(c->device, c->d_text, (size_t)c->n_bytes + 256);
+    pool_free(c->device, c->d_text_alloc, (size_t)c->n_bytes + 512);
     pool_free(c->device, c->d_offs, (size_t)(c->n_samples + 1) * 8);
     pool_free(c->device, c->d_order, (size_t)c->n_samples * 4 + 4);
     pool_free(c->device, c->d_bp, (size_t)c->n_bytes * 4 + 256);
@@ -882,7 +885,129 @@ static tgx_status ensure_reverse_trie(tgx_model* m) {
     int occ = 0;
     HIP_TRY(tgx::estep_max_blocks_per_cu(m->lm, &occ));
     m->estep_blocks_per_cu = std::max(1, std::min(occ, 16));
+    HIP_TRY(tgx::estep4_prepare());
     return TGX_OK;
+}
+
+// E-step on the four-snippets-per-wave kernels (estep4.hip).  Caller holds m->mu and has
+// built the reversed trie.
+static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout,
+                              uint64_t seed, double* expected, double* logz_sum) {
+    const uint64_t S = c->n_samples, N = c->n_bytes;
+    // the work list: every sample cut at multiples of snippet_len (src/prune.rs:83)
+    std::vector<uint64_t> soffs;
+    std::vector<uint32_t> ssample;
+    std::vector<uint64_t> sbase;
+    soffs.reserve(S + N / snippet_len + 2);
+    for (uint64_t i = 0; i < S; i++) {
+        const uint64_t b = c->h_offs[i], e = c->h_offs[i + 1];
+        for (uint64_t o = b; o < e; o += snippet_len) {
+            soffs.push_back(o);
+            ssample.push_back((uint32_t)i);
+            sbase.push_back(o - b);
+        }
+    }
+    const uint64_t K = soffs.size();
+    soffs.push_back(N);
+    // a snippet's end is the next snippet's start except across empty samples: offsets stay exact
+    // because snippets tile [0, N) in order
+    std::vector<uint32_t> order(K);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return soffs[a + 1] - soffs[a] > soffs[b + 1] - soffs[b];
+    });
+    const size_t n_rev = m->flat_rev.table.size();
+    // replicas of the expected-count array (see estep4_bwd_kernel): up to 256, within 512 MiB
+    uint32_t n_rep = 256;
+    while (n_rep > 1 && (size_t)n_rep * n_rev * 8 > (512ull << 20)) n_rep >>= 1;
+    const size_t abytes = (size_t)(N + K + 128) * 8, ebytes = (size_t)(n_rep + 1) * n_rev * 8 + 256, zbytes = (size_t)K * 8 + 256;
+    const size_t obytes = (size_t)(K + 1) * 8 + 256, ordbytes = (size_t)K * 4 + 256;
+    double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr, *d_zarr = nullptr;
+    uint64_t *d_soffs = nullptr, *d_sbase = nullptr;
+    uint32_t *d_order = nullptr, *d_ssample = nullptr;
+    auto cleanup = [&](tgx_status s2) {
+        pool_free(m->device, d_alpha, abytes);
+        pool_free(m->device, d_exp, ebytes);
+        pool_free(m->device, d_z, 256);
+        pool_free(m->device, d_zarr, zbytes);
+        pool_free(m->device, d_soffs, obytes);
+        pool_free(m->device, d_sbase, obytes);
+        pool_free(m->device, d_order, ordbytes);
+        pool_free(m->device, d_ssample, ordbytes);
+        return s2;
+    };
+    if (pool_alloc(m->device, abytes, (void**)&d_alpha) != hipSuccess ||
+        pool_alloc(m->device, ebytes, (void**)&d_exp) != hipSuccess ||
+        pool_alloc(m->device, 256, (void**)&d_z) != hipSuccess ||
+        pool_alloc(m->device, zbytes, (void**)&d_zarr) != hipSuccess ||
+        pool_alloc(m->device, obytes, (void**)&d_soffs) != hipSuccess ||
+        pool_alloc(m->device, obytes, (void**)&d_sbase) != hipSuccess ||
+        pool_alloc(m->device, ordbytes, (void**)&d_order) != hipSuccess ||
+        pool_alloc(m->device, ordbytes, (void**)&d_ssample) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (E-step scratch)"));
+    if (hipMemcpyAsync(d_soffs, soffs.data(), (K + 1) * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+        (K && hipMemcpyAsync(d_sbase, sbase.data(), K * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
+        (K && hipMemcpyAsync(d_order, order.data(), K * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
+        (K && hipMemcpyAsync(d_ssample, ssample.data(), K * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
+        hipMemsetAsync(d_exp, 0, ebytes, m->stream) != hipSuccess ||
+        hipMemsetAsync(d_z, 0, 256, m->stream) != hipSuccess ||
+        hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "E-step setup copies failed"));
+    tgx::Estep4Params p{};
+    p.text = c->d_text;
+    p.soffs = d_soffs;
+    p.order = d_order;
+    p.n_snips = K;
+    p.snip_sample = d_ssample;
+    p.snip_base = d_sbase;
+    p.trie_fwd = m->d_trie;
+    p.trie_rev = m->d_trie_rev;
+    p.root_fwd = m->flat.table[0].base & ~tgx::kTerminalBit;
+    p.root_rev = m->flat_rev.table[0].base & ~tgx::kTerminalBit;
+    p.alpha = d_alpha;
+    p.zarr = d_zarr;
+    p.expected_slot = d_exp;
+    p.n_slots_rev = (uint32_t)n_rev;
+    p.n_replicas = n_rep;
+    p.logz_sum = d_z;
+    p.err_snip = m->d_ctrl + 1;
+    p.dropout = dropout;
+    p.seed = seed;
+    time_begin(m, "estep4_fwd_kernel");
+    if (tgx::launch_estep4_fwd(p, (uint32_t)m->num_cus, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "estep4 forward launch failed"));
+    time_end(m);
+    time_begin(m, "estep4_bwd_kernel");
+    if (tgx::launch_estep4_bwd(p, (uint32_t)m->num_cus, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "estep4 backward launch failed"));
+    time_end(m);
+    double* d_sum = d_exp + (size_t)n_rep * n_rev;  // replica sums
+    time_begin(m, "estep4_reduce_kernel");
+    if (tgx::launch_estep4_reduce(d_exp, d_sum, (uint32_t)n_rev, n_rep, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "estep4 reduce launch failed"));
+    time_end(m);
+    std::vector<double> h(n_rev);
+    double hz = 0.0;
+    if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(h.data(), d_sum, n_rev * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(&hz, d_z, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "E-step pass failed: %s", hipGetErrorString(hipGetLastError())));
+    for (size_t t = 0; t < n_rev; t++) {
+        const uint32_t id = m->flat_rev.tokid[t];
+        if (id != tgx::kNoToken) expected[id] += h[t];
+    }
+    if (logz_sum) *logz_sum = hz;
+    m->last_alg_bytes = N + 8 * (S + 1) + 8ull * m->vocab_size;
+    const unsigned long long bad = m->h_ctrl[0];
+    if (bad != ~0ULL) {
+        const uint64_t smp = ssample[bad];
+        g_err_sample = smp;
+        g_err_pos = g_err_len = c->h_offs[smp + 1] - c->h_offs[smp];
+        return cleanup(fail(TGX_ERR_Z_NOT_NORMAL, "normalization constant is not a normal number (sample %llu, len=%llu)",
+                            (unsigned long long)smp, (unsigned long long)g_err_len));  // src/prune.rs:90-96
+    }
+    return cleanup(TGX_OK);
 }
 
 tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout,
@@ -897,6 +1022,11 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
     if (st != TGX_OK) return st;
     m->n_timed = 0;
     const uint64_t S = c->n_samples, N = c->n_bytes;
+    {
+        const char* force = getenv("TGX_PATH");
+        if (m->lm <= 16 && m->scores_finite && !(force && strcmp(force, "fused") == 0))
+            return estep_rows4(m, c, snippet_len, dropout, seed, expected, logz_sum);
+    }
     const size_t n_rev = m->flat_rev.table.size();
     const size_t abytes = (size_t)(N + S + 128) * 8, ebytes = n_rev * 8 + 256;
     double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr;
