@@ -59,6 +59,9 @@ __device__ __forceinline__ double estep_sweep(const EstepParams& P, const uint8_
                                               double* sc, uint32_t* hl, uint8_t* txt, double* abuf,
                                               double* __restrict__ Arow, double z, bool use_dropout) {
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(BACKWARD ? P.trie_rev : P.trie_fwd);
+    // one of n_replicas copies of the slot array (summed afterwards): hot tokens would
+    // otherwise serialise every wave's atomics
+    double* __restrict__ expected_slot = P.expected_slot + (size_t)(blockIdx.x % P.n_replicas) * P.n_slots_rev;
     const uint32_t root_base = BACKWARD ? P.root_rev : P.root_fwd;
     double acc = 0.0;    // value of the position this lane accumulates
     uint64_t reach = 1;  // bit j: lane j has received a push (coordinate 0: BOS / EOS, value 0.0)
@@ -142,7 +145,7 @@ __device__ __forceinline__ double estep_sweep(const EstepParams& P, const uint8_
                 const uint32_t hv = hl[kFront + i * LM + tj];
                 const double a = abuf[i + tj + 1u];
                 const double total = ((a + sv) + val) - z;
-                atomicAdd(&P.expected_slot[hv >> 6], exp(total));
+                atomicAdd(&expected_slot[hv >> 6], exp(total));
             }
             const bool first = !((reach >> lane) & 1ULL);
             const double merged = first ? pushed : log_sum_exp(acc, pushed);  // init_mode, lattice.rs:322-323

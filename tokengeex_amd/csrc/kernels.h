@@ -55,7 +55,8 @@ struct EstepParams {
     uint32_t lm;                    // max token length rounded up (<= 64)
     uint64_t snippet_len;           // 81920 in the reference (prune.rs:75)
     double* alpha;                  // f64[N + S + pad] forward values, sample s at offs[s] + s
-    double* expected_slot;          // f64[n_slots_rev] expected counts per reversed-trie slot
+    double* expected_slot;          // f64[n_replicas][n_slots_rev] expected counts per reversed-trie slot
+    uint32_t n_slots_rev, n_replicas;
     double* logz_sum;
     unsigned long long* err_sample; // min sample whose z is not normal (init ~0)
     double dropout;

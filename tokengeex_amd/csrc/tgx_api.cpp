@@ -1028,7 +1028,9 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
             return estep_rows4(m, c, snippet_len, dropout, seed, expected, logz_sum);
     }
     const size_t n_rev = m->flat_rev.table.size();
-    const size_t abytes = (size_t)(N + S + 128) * 8, ebytes = n_rev * 8 + 256;
+    uint32_t n_rep = 256;
+    while (n_rep > 1 && (size_t)n_rep * n_rev * 8 > (512ull << 20)) n_rep >>= 1;
+    const size_t abytes = (size_t)(N + S + 128) * 8, ebytes = (size_t)(n_rep + 1) * n_rev * 8 + 256;
     double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr;
     auto cleanup = [&](tgx_status s2) {
         pool_free(m->device, d_alpha, abytes);
@@ -1057,6 +1059,8 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
     p.snippet_len = snippet_len;
     p.alpha = d_alpha;
     p.expected_slot = d_exp;
+    p.n_slots_rev = (uint32_t)n_rev;
+    p.n_replicas = n_rep;
     p.logz_sum = d_z;
     p.err_sample = m->d_ctrl + 1;
     p.dropout = dropout;
@@ -1068,10 +1072,13 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
     if (tgx::launch_estep(p, blocks, m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "estep launch failed"));
     time_end(m);
+    double* d_sum = d_exp + (size_t)n_rep * n_rev;
+    if (tgx::launch_estep4_reduce(d_exp, d_sum, (uint32_t)n_rev, n_rep, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "estep reduce launch failed"));
     std::vector<double> h(n_rev);
     double hz = 0.0;
     if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
-        hipMemcpyAsync(h.data(), d_exp, n_rev * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(h.data(), d_sum, n_rev * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipMemcpyAsync(&hz, d_z, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipStreamSynchronize(m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "E-step pass failed: %s", hipGetErrorString(hipGetLastError())));
