@@ -5,8 +5,6 @@
 
 namespace tgx {
 
-enum { MODE_ENCODE = 0, MODE_COUNT = 1 };
-
 struct EncodeParams {
     const uint8_t* text;            // u8[N (+ pad)]
     const uint64_t* offs;           // u64[S+1]
@@ -16,17 +14,14 @@ struct EncodeParams {
     const uint32_t* tokid;          // u32[n_slots]
     uint32_t root_base;
     uint32_t n_slots;               // trie slots (guards the handle -> id lookup)
-    uint32_t cache_slots;           // unused (kept 0): an LDS copy of the hottest slots lost against more waves
     uint32_t lm;                    // max token length rounded up (<= 64)
     uint32_t* bp;                   // u32[N] back-pointer scratch
-    uint32_t* tmp;                  // u32[N] right-aligned ids per sample (MODE_ENCODE)
+    uint32_t* tmp;                  // u32[N] right-aligned ids per sample
     uint32_t* counts;               // u32[S] tokens per sample
     uint32_t* status;               // u32[S] 1 = end of sample reachable (encode4 -> trace)
     uint8_t* bp8;                   // u8[N] rows4 back-pointers: len - 1, 0xFF = unreachable
     const void* tokhash;            // TokHashEntry[mask + 1]: token bytes -> id (rows4 trace)
     uint32_t tokhash_mask;
-    unsigned long long* freq;       // u64[V] histogram (MODE_COUNT)
-    unsigned long long* next;       // work counter (zeroed before launch)
     unsigned long long* err_sample; // min failing sample (init ~0)
     double dropout;
     uint64_t seed;
@@ -41,7 +36,6 @@ struct CompactParams {
     const uint32_t* tmp;
     const uint64_t* out_offs;
     uint32_t* ids;
-    unsigned long long* next;
 };
 
 struct EstepParams {
@@ -113,13 +107,13 @@ hipError_t launch_estep(const EstepParams& p, uint32_t blocks, hipStream_t strea
 
 uint32_t encode_lds_bytes_per_block(uint32_t lm);
 uint32_t encode_waves_per_block(uint32_t lm);
-hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out);
-hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
+hipError_t encode_max_blocks_per_cu(uint32_t lm, int* out);
+hipError_t launch_encode(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 uint32_t encode4_group_bytes();
-uint32_t encode4_lds_bytes(int waves, int ppl, uint32_t cache_slots);
+uint32_t encode4_lds_bytes(int waves, int ppl);
 hipError_t encode4_prepare(bool dropout, int ppl);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream);
-hipError_t launch_trace(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream);
+hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);
 hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);
 

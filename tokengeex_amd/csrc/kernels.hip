@@ -218,7 +218,6 @@ __device__ __forceinline__ void block_fast(const WaveCtx& C, const uint8_t* __re
     if (lane >= 32u) bp[p - 1] = bpv;  // positions p0+32 .. p0+63
 }
 
-template <int MODE>
 __device__ __forceinline__ void trace_sample(const EncodeParams& P, uint32_t s, uint64_t beg, uint32_t n,
                                              uint32_t lane, const uint32_t* __restrict__ bp, uint32_t reach_n) {
     // follow the back-pointers from n (model.rs:113-126), 64 positions per hop group
@@ -247,12 +246,8 @@ __device__ __forceinline__ void trace_sample(const EncodeParams& P, uint32_t s, 
             const uint32_t slot = h >> 6;
             if (slot >= P.n_slots) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
             const uint32_t id = slot < P.n_slots ? P.tokid[slot] : 0u;
-            if (MODE == MODE_ENCODE) {
-                const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
-                P.tmp[cursor - 1 - above] = id;
-            } else {
-                atomicAdd(&P.freq[id], 1ULL);
-            }
+            const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
+            P.tmp[cursor - 1 - above] = id;
         }
         cursor -= cnt;
         total += cnt;
@@ -264,7 +259,7 @@ __device__ __forceinline__ void trace_sample(const EncodeParams& P, uint32_t s, 
 }
 
 // LMT = 0: generic (runtime LM <= 64); LMT = 16 / 32: fast path for full blocks.
-template <int MODE, int LMT>
+template <int LMT>
 __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -308,7 +303,7 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
         for (; p0 <= n; p0 += 64u)
             block_generic(C, text, n, s, p0, lane, LM, sc, hl, txt, bp, acc, bpv, reach, reach_n);
 
-        trace_sample<MODE>(P, s, beg, n, lane, bp, reach_n);
+        trace_sample(P, s, beg, n, lane, bp, reach_n);
     }
 }
 
@@ -591,7 +586,7 @@ __device__ __forceinline__ uint64_t tok_hash64_dev(uint32_t w0, uint32_t w1, uin
 
 // Back-trace + id emission for the rows4 path: one wave per sample, 1-byte back-pointers
 // (token length - 1), ids recovered from the token's bytes through the hash table.
-template <int MODE, bool STAMP>
+template <bool STAMP>
 __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wpb = blockDim.x >> 6;
@@ -687,13 +682,8 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
                 }
                 // cannot happen unless a kernel bug corrupted a back-pointer: report, do not fault
                 if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
-                if (MODE == MODE_ENCODE) {
-                    const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
-                    if (!(P.flags & 16u)) P.tmp[cursor - 1 - above] = id;  // flag: timing experiment
-                    else if (id == 0xFFFFFFFFu) P.tmp[0] = id;
-                } else {
-                    atomicAdd(&P.freq[id], 1ULL);
-                }
+                const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
+                P.tmp[cursor - 1 - above] = id;
             }
             TGX_STAMP(3)  // token bytes, hash, table probe, id store
             cursor -= cnt;
@@ -779,30 +769,25 @@ uint32_t encode_lds_bytes_per_block(uint32_t lm) {
 }
 
 typedef void (*encode_fn)(EncodeParams);
-static encode_fn pick_kernel(int mode, uint32_t lm) {
+static encode_fn pick_kernel(uint32_t lm) {
     const int t = lmt_for(lm);
-    if (mode == MODE_ENCODE) {
-        if (t == 16) return encode_kernel<MODE_ENCODE, 16>;
-        if (t == 32) return encode_kernel<MODE_ENCODE, 32>;
-        return encode_kernel<MODE_ENCODE, 0>;
-    }
-    if (t == 16) return encode_kernel<MODE_COUNT, 16>;
-    if (t == 32) return encode_kernel<MODE_COUNT, 32>;
-    return encode_kernel<MODE_COUNT, 0>;
+    if (t == 16) return encode_kernel<16>;
+    if (t == 32) return encode_kernel<32>;
+    return encode_kernel<0>;
 }
 
-hipError_t launch_encode(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream) {
+hipError_t launch_encode(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {
     const uint32_t lds = encode_lds_bytes_per_block(p.lm);
     const dim3 block(64u * encode_waves_per_block(p.lm));
-    hipLaunchKernelGGL(pick_kernel(mode, p.lm), dim3(blocks), block, lds, stream, p);
+    hipLaunchKernelGGL(pick_kernel(p.lm), dim3(blocks), block, lds, stream, p);
     return hipGetLastError();
 }
 
-hipError_t encode_max_blocks_per_cu(uint32_t lm, int mode, int* out) {
+hipError_t encode_max_blocks_per_cu(uint32_t lm, int* out) {
     const uint32_t lds = encode_lds_bytes_per_block(lm);
     const int threads = (int)(64u * encode_waves_per_block(lm));
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
-    encode_fn fn = pick_kernel(mode, lm);
+    encode_fn fn = pick_kernel(lm);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -818,9 +803,7 @@ static encode4_fn pick_encode4(bool dropout, int ppl, bool stamp = false) {
     return dropout ? encode4_kernel<true, 4, false> : encode4_kernel<false, 4, false>;
 }
 uint32_t encode4_group_bytes() { return kRows4GroupBytes; }
-uint32_t encode4_lds_bytes(int waves, int ppl, uint32_t cache_slots) {
-    return cache_slots * 16u + (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes;
-}
+uint32_t encode4_lds_bytes(int waves, int ppl) { return (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes; }
 hipError_t encode4_prepare(bool dropout, int ppl) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(pick_encode4(dropout, ppl)),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -829,20 +812,18 @@ hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t bl
     if (p.stamps) {
         encode4_fn fn = pick_encode4(false, 1, true);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), encode4_lds_bytes(waves, 1, p.cache_slots), stream, p);
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), encode4_lds_bytes(waves, 1), stream, p);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(pick_encode4(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * (uint32_t)waves),
-                       encode4_lds_bytes(waves, ppl, p.cache_slots), stream, p);
+                       encode4_lds_bytes(waves, ppl), stream, p);
     return hipGetLastError();
 }
-hipError_t launch_trace(const EncodeParams& p, int mode, uint32_t blocks, hipStream_t stream) {
+hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {
     if (p.stamps)
-        hipLaunchKernelGGL((trace_kernel<MODE_ENCODE, true>), dim3(blocks), dim3(256), 0, stream, p);
-    else if (mode == MODE_ENCODE)
-        hipLaunchKernelGGL((trace_kernel<MODE_ENCODE, false>), dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((trace_kernel<MODE_COUNT, false>), dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -117,7 +117,7 @@ struct tgx_model {
     unsigned long long* h_ctrl = nullptr;  // pinned: [0] err sample, [1] total tokens
     hipStream_t stream = nullptr;
     int num_cus = 0;
-    int blocks_per_cu[2] = {0, 0};
+    int blocks_per_cu = 0;  // encode_kernel (one sample per wave)
     // E-step only (built on first use): trie of the reversed tokens
     std::vector<uint8_t> vocab_bytes;
     std::vector<uint64_t> vocab_offs;
@@ -211,17 +211,16 @@ tgx_status ensure_scratch(tgx_corpus* c) {
     return TGX_OK;
 }
 
-uint32_t grid_blocks(const tgx_model* m, int mode, uint64_t n_samples) {
+uint32_t grid_blocks(const tgx_model* m, uint64_t n_samples) {
     const uint64_t wpb = tgx::encode_waves_per_block(m->lm);
     uint64_t want = (n_samples + wpb - 1) / wpb;
-    uint64_t cap = (uint64_t)m->num_cus * (uint64_t)std::max(1, m->blocks_per_cu[mode]);
+    uint64_t cap = (uint64_t)m->num_cus * (uint64_t)std::max(1, m->blocks_per_cu);
     return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
 }
 
 // Runs the wave-per-sample kernel over the corpus; on return (stream synced)
 // h_ctrl[0] = min failing sample (~0 if none).
-tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropout, uint64_t seed,
-                             unsigned long long* d_freq) {
+tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64_t seed) {
     tgx_status st = ensure_scratch(c);
     if (st != TGX_OK) return st;
     HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));
@@ -243,13 +242,12 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
     p.bp8 = reinterpret_cast<uint8_t*>(c->d_bp);  // the rows4 path uses the scratch row as bytes
     p.tokhash = m->d_tokhash;
     p.tokhash_mask = m->tokhash.mask;
-    p.freq = d_freq;
-    p.next = m->d_ctrl;
     p.err_sample = m->d_ctrl + 1;
     p.dropout = dropout;
     p.seed = seed;
     {
-        const char* f = getenv("TGX_FLAGS");  // timing experiments only; results are wrong when set
+        // timing experiments (tools/ablate.py) — results are WRONG when set; honoured only with TGX_DEBUG=1
+        const char* f = debug_on() ? getenv("TGX_FLAGS") : nullptr;
         p.flags = f ? (uint32_t)atoi(f) : 0u;
     }
     // TGX_PATH=fused forces the one-sample-per-wave kernel (A/B timing, tests of both paths)
@@ -276,7 +274,6 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
             if (v >= 1 && v <= 8) bpc = v;
         }
         while (waves > 1 && (uint32_t)(waves * ppl) * tgx::encode4_group_bytes() > (160u * 1024u) / (uint32_t)bpc) waves--;
-        p.cache_slots = 0;  // the LDS trie cache lost against more waves (see kernels.hip)
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
             1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
@@ -311,14 +308,14 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
         unsigned long long* d_tstamps = nullptr;
         const size_t n_twaves = (size_t)blocks_t * 4;
         if (const char* e = getenv("TGX_STAMPS")) {
-            if (*e == '2' && mode == tgx::MODE_ENCODE) {
+            if (*e == '2') {
                 HIP_TRY(hipMalloc((void**)&d_tstamps, n_twaves * 64));
                 HIP_TRY(hipMemsetAsync(d_tstamps, 0, n_twaves * 64, m->stream));
                 p.stamps = d_tstamps;
             }
         }
-        time_begin(m, mode == tgx::MODE_ENCODE ? "trace_kernel" : "trace_count_kernel");
-        HIP_TRY(tgx::launch_trace(p, mode, blocks_t, m->stream));
+        time_begin(m, "trace_kernel");
+        HIP_TRY(tgx::launch_trace(p, blocks_t, m->stream));
         time_end(m);
         if (d_tstamps) {
             std::vector<unsigned long long> h(n_twaves * 8);
@@ -335,8 +332,8 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, int mode, double dropo
             p.stamps = nullptr;
         }
     } else {
-        time_begin(m, mode == tgx::MODE_ENCODE ? "encode_kernel" : "encode_count_kernel");
-        HIP_TRY(tgx::launch_encode(p, mode, grid_blocks(m, mode, c->n_samples), m->stream));
+        time_begin(m, "encode_kernel");
+        HIP_TRY(tgx::launch_encode(p, grid_blocks(m, c->n_samples), m->stream));
         time_end(m);
     }
     return TGX_OK;
@@ -448,10 +445,10 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
         HIP_TRY_M(hipEventCreate(&m->timed[i].start));
         HIP_TRY_M(hipEventCreate(&m->timed[i].stop));
     }
-    for (int mode = 0; mode < 2; mode++) {
+    {
         int occ = 0;
-        HIP_TRY_M(tgx::encode_max_blocks_per_cu(m->lm, mode, &occ));
-        m->blocks_per_cu[mode] = std::max(1, std::min(occ, 16));
+        HIP_TRY_M(tgx::encode_max_blocks_per_cu(m->lm, &occ));
+        m->blocks_per_cu = std::max(1, std::min(occ, 16));
     }
     for (int d = 0; d < 2; d++)
         for (int q = 0; q < 3; q++) HIP_TRY_M(tgx::encode4_prepare(d == 1, 1 << q));
@@ -629,7 +626,7 @@ static tgx_status encode_corpus_locked(tgx_model* m, tgx_corpus* c, double dropo
     if (pool_alloc(m->device, (size_t)(S + 1) * 8, (void**)&r->d_offs) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (result offsets)"));
 
-    tgx_status st = run_encode_kernel(m, c, tgx::MODE_ENCODE, dropout, seed, nullptr);
+    tgx_status st = run_encode_kernel(m, c, dropout, seed);
     if (st != TGX_OK) return cleanup(st);
     time_begin(m, "scan_counts_kernel");
     if (tgx::launch_scan(c->d_counts, r->d_offs, S, m->stream) != hipSuccess)
@@ -654,7 +651,6 @@ static tgx_status encode_corpus_locked(tgx_model* m, tgx_corpus* c, double dropo
     cp.tmp = c->d_tmp;
     cp.out_offs = r->d_offs;
     cp.ids = r->d_ids;
-    cp.next = m->d_ctrl;
     time_begin(m, "compact_kernel");
     uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((S + 3) / 4, (uint64_t)m->num_cus * 8));
     if (tgx::launch_compact(cp, blocks, m->stream) != hipSuccess)

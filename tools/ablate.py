@@ -1,6 +1,7 @@
 """Timing ablations of the encode kernel (results are WRONG when TGX_FLAGS != 0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["TGX_DEBUG"] = "1"  # TGX_FLAGS is only honoured in debug mode
 import numpy as np
 import tokengeex_amd as tgx
 from tokengeex_amd import synth
