@@ -155,6 +155,25 @@ tgx_status tgx_estep(tgx_model *m, tgx_corpus *c, uint64_t snippet_len, double d
 
 void tgx_free(void *p);
 
+/* ---- prune host logic (no device needed) ---------------------
+ * The O(V) steps of ModelVocabularyPruner between the corpus passes above. */
+double tgx_digamma(double x);                                        /* src/prune.rs:322-335 */
+/* run_m_step — src/prune.rs:124-170: tokens with expected < 0.5 and !keep are dropped, the
+ * others get score = digamma(max(freq, 0.5)) - digamma(sum).  out_* need room for V entries. */
+tgx_status tgx_prune_m_step(const double *expected, const uint8_t *keep, uint32_t vocab_size,
+                            uint32_t *out_idx, double *out_score, uint32_t *out_n);
+/* prune_vocab, first half — src/prune.rs:179-203 over Lattice::nbest(2) (src/lattice.rs:152-238):
+ * always_keep[V]; alternatives in CSR form, *alt_ids malloc'd (tgx_free). */
+tgx_status tgx_prune_alternatives(const tgx_flat_trie *trie, const uint8_t *bytes, const uint64_t *offs,
+                                  const double *scores, uint32_t vocab_size, uint8_t *always_keep,
+                                  uint32_t *alt_offs, uint32_t **alt_ids);
+/* prune_vocab, second half — src/prune.rs:246-318: ids of the pruned vocabulary in its final
+ * order (score descending).  out_idx needs room for V entries. */
+tgx_status tgx_prune_select(const uint64_t *freq, const uint8_t *keep, const uint8_t *always_keep,
+                            const uint32_t *alt_offs, const uint32_t *alt_ids, const double *scores,
+                            uint32_t vocab_size, uint64_t n_samples, uint32_t pruned_size,
+                            uint32_t *out_idx, uint32_t *out_n);
+
 /* ---- measurement ---------------------------------------------------------- */
 /* Per-kernel GPU time of the last pass on this model's stream, measured with
  * hipEvents recorded on that stream around each launch.  names[i] are static

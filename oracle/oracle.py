@@ -25,10 +25,9 @@ _f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (no-op when the .so is newer than the source)."""
-    src = os.path.join(_HERE, "tgx_oracle.c")
-    hdr = os.path.join(_HERE, "tgx_oracle.h")
+    srcs = [os.path.join(_HERE, f) for f in ("tgx_oracle.c", "tgx_prune_oracle.c", "tgx_oracle.h")]
     if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_SO) >= max(os.path.getmtime(f) for f in srcs)):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
     return _SO
@@ -77,6 +76,16 @@ def lib() -> C.CDLL:
     L.orc_split_specials.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.orc_free.argtypes = [C.c_void_p]
+    L.orc_digamma.restype = C.c_double
+    L.orc_digamma.argtypes = [C.c_double]
+    L.orc_m_step.restype = C.c_int
+    L.orc_m_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, _u32p]
+    L.orc_prune_alternatives.restype = C.c_int
+    L.orc_prune_alternatives.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.POINTER(_u32p)]
+    L.orc_prune_select.restype = C.c_int
+    L.orc_prune_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, _u32p]
     _lib = L
     return L
 
@@ -227,3 +236,48 @@ def split_specials(text: bytes, specials: list[bytes]) -> list[tuple[bytes, bool
     if k == C.c_size_t(-1).value:
         raise ValueError("empty special token")
     return [(text[int(st[i]):int(en[i])], bool(sp[i] >= 0)) for i in range(k)]
+
+
+# ---- host half of `prune` (tgx_prune_oracle.c) ----
+
+def digamma(x: float) -> float:
+    return lib().orc_digamma(x)
+
+
+def m_step(expected, keep):
+    """src/prune.rs:124-170 -> (status, ids, scores)."""
+    expected = np.ascontiguousarray(expected, dtype=np.float64)
+    keep = np.ascontiguousarray(keep, dtype=np.uint8)
+    V = expected.shape[0]
+    idx, sc, n = np.zeros(max(V, 1), np.uint32), np.zeros(max(V, 1), np.float64), C.c_uint32()
+    st = lib().orc_m_step(_ptr(expected), _ptr(keep), V, _ptr(idx), _ptr(sc), C.byref(n))
+    return st, idx[:n.value].copy(), sc[:n.value].copy()
+
+
+def prune_alternatives(model: "OracleModel"):
+    """src/prune.rs:179-203 -> (always_keep, alt_offs, alt_ids)."""
+    V = model.vocab_size
+    always_keep = np.zeros(V, np.uint8)
+    alt_offs = np.zeros(V + 1, np.uint32)
+    p = _u32p()
+    lib().orc_prune_alternatives(model._h, _ptr(model._flat), _ptr(model._offs), _ptr(model.scores), V,
+                                 _ptr(always_keep), _ptr(alt_offs), C.byref(p))
+    k = int(alt_offs[V])
+    ids = np.ctypeslib.as_array(p, shape=(max(k, 1),))[:k].copy()
+    lib().orc_free(p)
+    return always_keep, alt_offs, ids
+
+
+def prune_select(freq, keep, always_keep, alt_offs, alt_ids, scores, n_samples: int, pruned_size: int):
+    """src/prune.rs:246-318 -> (status, ids in final order)."""
+    freq = np.ascontiguousarray(freq, dtype=np.uint64)
+    keep = np.ascontiguousarray(keep, dtype=np.uint8)
+    always_keep = np.ascontiguousarray(always_keep, dtype=np.uint8)
+    alt_offs = np.ascontiguousarray(alt_offs, dtype=np.uint32)
+    alt_ids = np.ascontiguousarray(alt_ids, dtype=np.uint32)
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    V = freq.shape[0]
+    out, n = np.zeros(max(V, 1), np.uint32), C.c_uint32()
+    st = lib().orc_prune_select(_ptr(freq), _ptr(keep), _ptr(always_keep), _ptr(alt_offs), _ptr(alt_ids),
+                                _ptr(scores), V, n_samples, pruned_size, _ptr(out), C.byref(n))
+    return st, out[:n.value].copy()

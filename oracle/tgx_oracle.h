@@ -98,6 +98,18 @@ size_t orc_split_specials(const uint8_t *text, size_t n, const uint8_t *sp_bytes
 
 void orc_free(void *p);
 
+/* ---- host half of `prune` (tgx_prune_oracle.c) ---- */
+double orc_digamma(double x);                                   /* src/prune.rs:322-335 */
+int orc_m_step(const double *expected, const uint8_t *keep, uint32_t vocab_size, uint32_t *out_idx,
+               double *out_score, uint32_t *out_n);             /* src/prune.rs:124-170 */
+int orc_prune_alternatives(const orc_model *m, const uint8_t *bytes, const uint64_t *offs,
+                           const double *scores, uint32_t vocab_size, uint8_t *always_keep,
+                           uint32_t *alt_offs, uint32_t **alt_ids); /* src/prune.rs:179-203 */
+int orc_prune_select(const uint64_t *freq, const uint8_t *keep, const uint8_t *always_keep,
+                     const uint32_t *alt_offs, const uint32_t *alt_ids, const double *scores,
+                     uint32_t vocab_size, uint64_t n_samples, uint32_t pruned_size, uint32_t *out_idx,
+                     uint32_t *out_n);                          /* src/prune.rs:246-318 */
+
 #ifdef __cplusplus
 }
 #endif

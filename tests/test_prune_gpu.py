@@ -1,0 +1,48 @@
+"""End-to-end `prune` (src/prune.rs:23-57) on the GPU path against the same loop driven through the
+oracle: E-step + frequency pass on the device, M-step / alternatives / selection on the host."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc
+from tokengeex_amd.prune import ModelVocabularyPruner
+
+from util import corpus_and_vocab
+
+
+def oracle_prune(vocab, flat, offs, vocab_size, shrink_factor, em_subiters, dropout, seed=0):
+    """The reference loop over oracle functions only (checker)."""
+    S = offs.shape[0] - 1
+    while len(vocab) > vocab_size:
+        for _ in range(em_subiters):
+            m = orc.OracleModel([t[0] for t in vocab], [t[1] for t in vocab])
+            seed += 1
+            st, expected, _, _ = m.estep_flat(flat, offs, 81920, dropout, seed, threads=8)
+            assert st == orc.OK
+            st, idx, sc = orc.m_step(expected, np.array([1 if t[2] else 0 for t in vocab], np.uint8))
+            assert st == 0
+            vocab = [(vocab[int(i)][0], float(s), vocab[int(i)][2]) for i, s in zip(idx, sc)]
+        m = orc.OracleModel([t[0] for t in vocab], [t[1] for t in vocab])
+        pruned_size = max(int(len(vocab) * shrink_factor), vocab_size)
+        ak, ao, ai = orc.prune_alternatives(m)
+        freq = m.count_tokens_flat(flat, offs, threads=8)
+        st, out = orc.prune_select(freq, np.array([1 if t[2] else 0 for t in vocab], np.uint8), ak, ao, ai,
+                                   m.scores, S, pruned_size)
+        assert st == 0
+        vocab = [vocab[int(i)] for i in out]
+    return vocab
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.05])
+def test_prune_end_to_end_matches_oracle_loop(dropout):
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 4000, 16, max_len=16384)
+    vocab = [(t, float(s), len(t) == 1) for t, s in zip(toks, scores)]
+    pruner = ModelVocabularyPruner(800, 0.75, 2, dropout)
+    got = pruner.prune(vocab, flat, offs)
+    want = oracle_prune(vocab, flat, offs, 800, 0.75, 2, dropout)
+    assert len(got) == 800
+    assert [t[0] for t in got] == [t[0] for t in want]
+    np.testing.assert_allclose([t[1] for t in got], [t[1] for t in want], rtol=1e-7, atol=1e-9)
+    assert [t[2] for t in got] == [t[2] for t in want]
+    assert len(pruner.timings) >= 2 and all(r["to"] < r["from"] for r in pruner.timings)

@@ -58,6 +58,10 @@ SYMBOLS = {
     "tgx_count_pairs": (_i, [_vp, _vp, _pvp, _pvp, _pu64]),
     "tgx_estep": (_i, [_vp, _vp, _u64, _d, _u64, _vp, C.POINTER(C.c_double)]),
     "tgx_free": (None, [_vp]),
+    "tgx_digamma": (_d, [_d]),
+    "tgx_prune_m_step": (_i, [_vp, _vp, _u32, _vp, _vp, C.POINTER(C.c_uint32)]),
+    "tgx_prune_alternatives": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _pvp]),
+    "tgx_prune_select": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u64, _u32, _vp, C.POINTER(C.c_uint32)]),
     "tgx_last_kernel_times": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i]),
     "tgx_last_algorithmic_bytes": (_u64, [_vp]),
 }
@@ -323,6 +327,54 @@ class FlatTrie:
         check, base, tokid = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
         lib.tgx_flat_trie_copy(self._h, ptr(check), ptr(base), ptr(tokid))
         return check, base, tokid
+
+
+    # ---- host half of `prune` (src/prune.rs) ----
+    def prune_alternatives(self, tokens: list[bytes], scores) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """-> (always_keep u8[V], alt_offs u32[V+1], alt_ids u32[...]) — src/prune.rs:179-203."""
+        flat, offs = pack(tokens)
+        sc = np.ascontiguousarray(scores, dtype=np.float64)
+        V = len(tokens)
+        always_keep = np.zeros(V, np.uint8)
+        alt_offs = np.zeros(V + 1, np.uint32)
+        p = C.c_void_p()
+        check(lib.tgx_prune_alternatives(self._h, ptr(flat) if flat.size else None, ptr(offs), ptr(sc), V,
+                                         ptr(always_keep), ptr(alt_offs), C.byref(p)))
+        k = int(alt_offs[V])
+        ids = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(k, 1),))[:k].copy()
+        lib.tgx_free(p)
+        return always_keep, alt_offs, ids
+
+
+def digamma(x: float) -> float:
+    return lib.tgx_digamma(x)
+
+
+def prune_m_step(expected: np.ndarray, keep: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """run_m_step — src/prune.rs:124-170 -> (surviving ids, new scores)."""
+    expected = np.ascontiguousarray(expected, dtype=np.float64)
+    keep = np.ascontiguousarray(keep, dtype=np.uint8)
+    V = expected.shape[0]
+    idx, sc, n = np.zeros(max(V, 1), np.uint32), np.zeros(max(V, 1), np.float64), C.c_uint32()
+    check(lib.tgx_prune_m_step(ptr(expected), ptr(keep), V, ptr(idx), ptr(sc), C.byref(n)))
+    return idx[:n.value].copy(), sc[:n.value].copy()
+
+
+def prune_select(freq, keep, always_keep, alt_offs, alt_ids, scores, n_samples: int,
+                 pruned_size: int) -> np.ndarray:
+    """Loss-based selection — src/prune.rs:246-318 -> ids of the pruned vocabulary, final order."""
+    freq = np.ascontiguousarray(freq, dtype=np.uint64)
+    keep = np.ascontiguousarray(keep, dtype=np.uint8)
+    always_keep = np.ascontiguousarray(always_keep, dtype=np.uint8)
+    alt_offs = np.ascontiguousarray(alt_offs, dtype=np.uint32)
+    alt_ids = np.ascontiguousarray(alt_ids, dtype=np.uint32)
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    V = freq.shape[0]
+    out, n = np.zeros(max(V, 1), np.uint32), C.c_uint32()
+    check(lib.tgx_prune_select(ptr(freq), ptr(keep), ptr(always_keep), ptr(alt_offs),
+                               ptr(alt_ids) if alt_ids.size else None, ptr(scores), V, n_samples,
+                               pruned_size, ptr(out), C.byref(n)))
+    return out[:n.value].copy()
 
 
 def dropout_u01(seed: int, sample: int, pos: int, length: int) -> float:

@@ -492,7 +492,7 @@ tgx_status tgx_common_prefix_search(const tgx_model* m, const uint8_t* s, uint64
 
 // ---- host-only trie introspection ----------------------------------------------
 
-struct tgx_flat_trie {
+struct tgx_flat_trie {  // also defined in prune_host.cpp (same layout)
     tgx::FlatTrie flat;
 };
 
