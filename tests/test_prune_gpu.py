@@ -42,7 +42,16 @@ def test_prune_end_to_end_matches_oracle_loop(dropout):
     got = pruner.prune(vocab, flat, offs)
     want = oracle_prune(vocab, flat, offs, 800, 0.75, 2, dropout)
     assert len(got) == 800
-    assert [t[0] for t in got] == [t[0] for t in want]
-    np.testing.assert_allclose([t[1] for t in got], [t[1] for t in want], rtol=1e-7, atol=1e-9)
-    assert [t[2] for t in got] == [t[2] for t in want]
+    # Same tokens, same scores to E-step tolerance, same keep flags.  The ORDER of tokens whose expected
+    # counts are equal up to f64 summation noise is not comparable (the reference's own rayon reduction
+    # order, src/prune.rs:104-113, makes it run-dependent too), so compare as token -> (score, keep) maps
+    # and check each result is ordered by score.
+    gd, wd = {t[0]: t for t in got}, {t[0]: t for t in want}
+    assert len(gd) == len(got) and sorted(gd) == sorted(wd)
+    for k in gd:
+        assert gd[k][2] == wd[k][2]
+        assert abs(gd[k][1] - wd[k][1]) <= 1e-7 * abs(wd[k][1]) + 1e-9, k
+    assert np.all(np.diff([t[1] for t in got]) <= 0)
+    moved = sum(1 for a, b in zip(got, want) if a[0] != b[0])
+    assert moved <= len(got) // 10  # only near-tie neighbours may swap
     assert len(pruner.timings) >= 2 and all(r["to"] < r["from"] for r in pruner.timings)

@@ -55,6 +55,12 @@ __device__ __forceinline__ uint32_t sel_u32(uint64_t mask, uint32_t t, uint32_t 
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(mask));
     return r;
 }
+template <int IMM>  // mask ? IMM : f, IMM an inline constant (0..64)
+__device__ __forceinline__ uint32_t sel_imm_u32(uint64_t mask, uint32_t f) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "n"(IMM), "s"(mask));
+    return r;
+}
 __device__ __forceinline__ double sel_f64(uint64_t mask, double t, double f) {
     const uint64_t tb = (uint64_t)__double_as_longlong(t), fb = (uint64_t)__double_as_longlong(f);
     const uint32_t lo = sel_u32(mask, (uint32_t)tb, (uint32_t)fb);
@@ -68,15 +74,53 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t row_bcast_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
 }
+// One v_mov_b64 with DPP (gfx90a+ allow row_newbcast on the 64-bit move) instead of two
+// 32-bit DPP moves plus the two moves that initialise their destinations.  The s_nop covers
+// the "VALU write -> DPP read" hazard, which the compiler does not track through inline asm.
 template <int U>
 __device__ __forceinline__ double row_bcast_f64(double v) {
-    const uint64_t b = (uint64_t)__double_as_longlong(v);
-    const uint32_t lo = row_bcast_u32<0x150 + U>((uint32_t)b);
-    const uint32_t hi = row_bcast_u32<0x150 + U>((uint32_t)(b >> 32));
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+    double r;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "=v"(r) : "v"(v), "n"(U));
+    return r;
 }
 
 constexpr uint64_t kRowLane0 = 0x0001000100010001ULL;  // lane 0 of each 16-lane row
+
+// Work queues.  One lane adds to a global counter and the whole wave reads the result.  Written as
+// `if (lane == 0) got = atomicAdd(..)` followed by readfirstlane, the compiler's control-flow
+// structurizer has twice produced loops that re-use a stale value instead of repeating the atomic
+// (the wave then processes unit 0 forever), so the EXEC mask is narrowed by hand and the compiler sees
+// one opaque instruction.  Lane 0 of a wave is always active here (full waves, uniform control flow).
+__device__ __forceinline__ uint64_t wave_fetch_add(unsigned long long* counter, uint32_t n) {
+    uint64_t got, saved;
+    const uint64_t inc = n;
+    const uint32_t zero = 0;
+    asm volatile(
+        "s_mov_b64 %1, exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add_x2 %0, %2, %3, %4 sc0\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(got), "=&s"(saved) : "v"(zero), "v"(inc), "s"(counter) : "memory");
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)got);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(got >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Work distribution of the four-rows-per-wave kernels: rows that finished their unit claim the next
+// index of the longest-first order — one atomic per wave and trip.  Rows therefore run out of work
+// together whatever the mix of lengths (a static split leaves the rows that drew the long units
+// running alone at the end).  Returns the claimed index for rows with need_new set, ~0 for the others.
+__device__ __forceinline__ uint64_t claim_rows(unsigned long long* queue, bool need_new, uint32_t r) {
+    const uint64_t want = __builtin_amdgcn_ballot_w64(need_new) & kRowLane0;  // bit 16 r: row r needs one
+    uint64_t k = ~0ull;
+    if (want != 0) {  // wave-uniform
+        const uint64_t base = wave_fetch_add(queue, (uint32_t)__builtin_popcountll(want));
+        if (need_new) k = base + (uint64_t)__builtin_popcountll(want & ((1ull << (r * 16u)) - 1ull));
+    }
+    return k;
+}
 
 // One 16-byte trie record in ONE load: the empty asm makes all four words live at
 // once (otherwise the compiler splits the load into three dependent round trips).

@@ -85,9 +85,6 @@ __global__ __launch_bounds__(256) void estep4_fwd_kernel(Estep4Params P) {
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie_fwd);
     double* sc = reinterpret_cast<double*>(smem + (size_t)wave * (kE4Entries * 8u));
-    const uint32_t wpb = blockDim.x >> 6;
-    const uint64_t n_rows = (uint64_t)gridDim.x * wpb * 4u;
-    uint64_t k = ((uint64_t)blockIdx.x * wpb + wave) * 4u + r;
 
     const double ninf = -__builtin_huge_val();
     uint32_t s = 0, n = 0, p0 = 0, smp = 0;
@@ -97,6 +94,7 @@ __global__ __launch_bounds__(256) void estep4_fwd_kernel(Estep4Params P) {
     double zsum = 0.0;
 
     for (;;) {
+        const uint64_t k = claim_rows(P.queue_fwd, need_new, r);  // longest-first, dynamic
         if (need_new) {
             live = k < P.n_snips;
             if (live) {
@@ -107,7 +105,6 @@ __global__ __launch_bounds__(256) void estep4_fwd_kernel(Estep4Params P) {
                     smp = P.snip_sample[s];
                     sbase = P.snip_base[s];
                 }
-                k += n_rows;
             }
             p0 = 0;
             acc = (l == 0u) ? 0.0 : ninf;  // BOS: alpha = 0 (lattice.rs:96-101, 267)
@@ -217,9 +214,6 @@ __global__ __launch_bounds__(256) void estep4_bwd_kernel(Estep4Params P) {
     unsigned char* wbase = smem + (size_t)wave * (kE4Entries * 12u);
     double* sc = reinterpret_cast<double*>(wbase);
     uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + kE4Entries * 8u);
-    const uint32_t wpb = blockDim.x >> 6;
-    const uint64_t n_rows = (uint64_t)gridDim.x * wpb * 4u;
-    uint64_t k = ((uint64_t)blockIdx.x * wpb + wave) * 4u + r;
     // expected counts go to one of n_replicas copies of the slot array (reduced afterwards):
     // a handful of very frequent tokens would otherwise serialise every wave's atomics
     double* __restrict__ expected_slot = P.expected_slot + (size_t)(blockIdx.x % P.n_replicas) * P.n_slots_rev;
@@ -231,6 +225,7 @@ __global__ __launch_bounds__(256) void estep4_bwd_kernel(Estep4Params P) {
     double acc = ninf, z = 0.0, a_cur = 0.0, a_nxt = 0.0;
 
     for (;;) {
+        const uint64_t k = claim_rows(P.queue_bwd, need_new, r);  // longest-first, dynamic
         if (need_new) {
             live = k < P.n_snips;
             if (live) {
@@ -242,7 +237,6 @@ __global__ __launch_bounds__(256) void estep4_bwd_kernel(Estep4Params P) {
                     smp = P.snip_sample[s];
                     sbase = P.snip_base[s];
                 }
-                k += n_rows;
             }
             y0 = 0;
             acc = (l == 0u) ? 0.0 : ninf;  // EOS: beta = 0

@@ -23,6 +23,7 @@ struct EncodeParams {
     const void* tokhash;            // TokHashEntry[mask + 1]: token bytes -> id (rows4 trace)
     uint32_t tokhash_mask;
     unsigned long long* err_sample; // min failing sample (init ~0)
+    unsigned long long* queue;      // rows4: next unclaimed position of `order` (init 0)
     double dropout;
     uint64_t seed;
     uint32_t flags;                 // timing experiments only (TGX_FLAGS env): see kernels.hip
@@ -91,6 +92,8 @@ struct Estep4Params {
     uint32_t n_slots_rev, n_replicas;
     double* logz_sum;
     unsigned long long* err_snip;   // min snippet whose z is not normal (init ~0)
+    unsigned long long* queue_fwd;  // next unclaimed position of `order`, forward / backward kernel (init 0)
+    unsigned long long* queue_bwd;
     double dropout;
     uint64_t seed;
 };
@@ -110,9 +113,8 @@ uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int* out);
 hipError_t launch_encode(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 uint32_t encode4_group_bytes();
-uint32_t encode4_lds_bytes(int waves, int ppl);
-hipError_t encode4_prepare(bool dropout, int ppl);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream);
+uint32_t encode4_lds_bytes(int waves, int ppl);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);
 hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);

@@ -335,18 +335,25 @@ constexpr uint32_t kNoStep = 0xFFu;  // "nothing pushed into this accumulator ye
 // gives the token length ((l - U - 1) & 15) + 1, the only thing the trace needs: the
 // token id is looked up from the token's bytes (hash table), so no trie handle travels
 // through LDS and the match buffer is 8 bytes per (position, length).
+//
+// Step U finalises position p0 + U (lane U of each row) and starts position p0 + U + 16 in
+// the same lane.  The final (winner step, high word of the score) pair of that lane is kept
+// in `fin` / `fhi`, and the lane is restarted by FORCING it to take this step's candidate
+// (the 16-byte token starting at p0 + U, or -inf) instead of resetting it first.  A forced
+// take of -inf leaves a meaningless winner step behind; the position is "not reached" iff its
+// final score is -inf, which is what the kept high word tells.  (Parking the pair in LDS with
+// an EXEC-masked store instead of two v_cndmask was tried: the LDS pipe is per CU, the VALUs
+// per SIMD, and the kernel got slower.)
 template <int U>
-__device__ __forceinline__ void relax4_step(double sv, double& acc, uint32_t& bpv, uint32_t& fin) {
+__device__ __forceinline__ void relax4_step(double sv, double& acc, uint32_t& bpv, uint32_t& fin, uint32_t& fhi) {
     constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
-    const double ninf = -__builtin_huge_val();
-    fin = sel_u32(MU, bpv, fin);             // winner step of position p0 + U is final now
     const double best = row_bcast_f64<U>(acc);
-    acc = sel_f64(MU, ninf, acc);            // lane U of each row now accumulates position p0 + U + 16
-    bpv = sel_u32(MU, kNoStep, bpv);
+    fin = sel_u32(MU, bpv, fin);
+    fhi = sel_u32(MU, (uint32_t)((uint64_t)__double_as_longlong(acc) >> 32), fhi);
     const double cand = best + sv;           // model.rs:98
-    const bool take = cand > acc;            // model.rs:101
-    acc = take ? cand : acc;
-    bpv = take ? (uint32_t)U : bpv;
+    const uint64_t take = __builtin_amdgcn_fcmp(cand, acc, 2 /* OGT: model.rs:101 */) | MU;
+    acc = sel_f64(take, cand, acc);
+    bpv = sel_imm_u32<U>(take, bpv);
 }
 
 // rows4 LDS: 1024 f64 scores (8 KiB) per wave and 16-position group — 20 waves per CU.
@@ -376,14 +383,12 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
-    // (An LDS copy of the hottest trie slots was tried — 81 % of the gathers hit 64 KiB of
-    // hottest-first slots — and lost: a walk step waits for its slowest lane, which still goes
-    // to L2, while the cache costs waves.  All of the CU's LDS goes to match buffers.)
+    // (An LDS copy of the hottest trie slots — 2048 slots take 3/4 of all gathers — was tried twice, per
+    // block and shared by one 16-wave block per CU, and lost both times: 21.2 ms against 19.7 ms at 1 GiB.
+    // A walk step still waits for its slowest lane, which goes to L2, and pays an extra LDS read and a
+    // select; the LDS pipe is as loaded as the gather path.)
     unsigned char* wbase = smem + (size_t)wave * (PPL * kRows4GroupBytes);
-
     const uint32_t wpb = blockDim.x >> 6;
-    const uint64_t n_rows = (uint64_t)gridDim.x * wpb * 4u;
-    uint64_t k = ((uint64_t)blockIdx.x * wpb + wave) * 4u + r;  // this row's next sample in the order
 
     // per-row state (identical in the 16 lanes of a row)
     uint32_t s = 0, n = 0, p0 = 0;
@@ -401,14 +406,19 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
 
     for (;;) {
         // ---- rows that finished their sample take the next one
-        if (need_new) {
-            live = k < P.n_samples;
-            if (live) {
-                s = P.order[k];
-                beg = P.offs[s];
-                n = (uint32_t)(P.offs[s + 1] - beg);
-                k += n_rows;
+        // ---- rows that finished their sample claim the next one (device_common.h: claim_rows)
+        {
+            const uint64_t k = claim_rows(P.queue, need_new, r);
+            if (need_new) {
+                live = k < P.n_samples;
+                if (live) {
+                    s = P.order[k];
+                    beg = P.offs[s];
+                    n = (uint32_t)(P.offs[s + 1] - beg);
+                }
             }
+        }
+        if (need_new) {
             p0 = 0;
             acc = (l == 0u) ? 0.0 : ninf;  // position 0: score 0, reachable
             bpv = kNoStep;
@@ -516,32 +526,36 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
 
         // ---- relax: 16*PPL static steps, four positions (one per row) per step.  All 16 LDS
         // reads of a group are issued before the dependent chain starts.
-        uint32_t fin[PPL];
+        uint32_t fin[PPL];   // winner step of this lane's position
+        bool reached[PPL];   // its best score is not -inf
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
             fin[g] = kNoStep;
+            reached[g] = false;
             if (P.flags & 2u) continue;
             // row (r*16 + U), column (l - 1) & 15: see relax4_step
             const double* scr = reinterpret_cast<const double*>(wbase + g * kRows4GroupBytes) + r * 256u + ((l - 1u) & 15u);
             double sv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) sv[u] = scr[u * 16];
-            relax4_step<0>(sv[0], acc, bpv, fin[g]);
-            relax4_step<1>(sv[1], acc, bpv, fin[g]);
-            relax4_step<2>(sv[2], acc, bpv, fin[g]);
-            relax4_step<3>(sv[3], acc, bpv, fin[g]);
-            relax4_step<4>(sv[4], acc, bpv, fin[g]);
-            relax4_step<5>(sv[5], acc, bpv, fin[g]);
-            relax4_step<6>(sv[6], acc, bpv, fin[g]);
-            relax4_step<7>(sv[7], acc, bpv, fin[g]);
-            relax4_step<8>(sv[8], acc, bpv, fin[g]);
-            relax4_step<9>(sv[9], acc, bpv, fin[g]);
-            relax4_step<10>(sv[10], acc, bpv, fin[g]);
-            relax4_step<11>(sv[11], acc, bpv, fin[g]);
-            relax4_step<12>(sv[12], acc, bpv, fin[g]);
-            relax4_step<13>(sv[13], acc, bpv, fin[g]);
-            relax4_step<14>(sv[14], acc, bpv, fin[g]);
-            relax4_step<15>(sv[15], acc, bpv, fin[g]);
+            uint32_t fhi = 0xFFF00000u;
+            relax4_step<0>(sv[0], acc, bpv, fin[g], fhi);
+            relax4_step<1>(sv[1], acc, bpv, fin[g], fhi);
+            relax4_step<2>(sv[2], acc, bpv, fin[g], fhi);
+            relax4_step<3>(sv[3], acc, bpv, fin[g], fhi);
+            relax4_step<4>(sv[4], acc, bpv, fin[g], fhi);
+            relax4_step<5>(sv[5], acc, bpv, fin[g], fhi);
+            relax4_step<6>(sv[6], acc, bpv, fin[g], fhi);
+            relax4_step<7>(sv[7], acc, bpv, fin[g], fhi);
+            relax4_step<8>(sv[8], acc, bpv, fin[g], fhi);
+            relax4_step<9>(sv[9], acc, bpv, fin[g], fhi);
+            relax4_step<10>(sv[10], acc, bpv, fin[g], fhi);
+            relax4_step<11>(sv[11], acc, bpv, fin[g], fhi);
+            relax4_step<12>(sv[12], acc, bpv, fin[g], fhi);
+            relax4_step<13>(sv[13], acc, bpv, fin[g], fhi);
+            relax4_step<14>(sv[14], acc, bpv, fin[g], fhi);
+            relax4_step<15>(sv[15], acc, bpv, fin[g], fhi);
+            reached[g] = fhi != 0xFFF00000u;  // high word of -inf
         }
         __builtin_amdgcn_wave_barrier();
         TGX_STAMP(3)  // relax
@@ -551,7 +565,7 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
         for (int g = 0; g < PPL; ++g)
             if (live && pg[g] >= 1u && pg[g] <= n) {
                 // winner pushed at step U = fin into lane l: token length ((l - U - 1) & 15) + 1
-                const uint8_t b = (fin[g] == kNoStep) ? (uint8_t)0xFF : (uint8_t)((l - fin[g] - 1u) & 15u);
+                const uint8_t b = reached[g] ? (uint8_t)((l - fin[g] - 1u) & 15u) : (uint8_t)0xFF;
                 __builtin_nontemporal_store(b, P.bp8 + beg + pg[g] - 1);
             }
         if (live) {
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
             if (left < SPAN) {  // position n lies in this iteration: the sample is done
 #pragma unroll
                 for (int g = 0; g < PPL; ++g)
-                    if (left == 16u * g + l) P.status[s] = (n == 0u || fin[g] != kNoStep) ? 1u : 0u;
+                    if (left == 16u * g + l) P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
                 need_new = true;
             } else {
                 p0 += SPAN;
@@ -598,6 +612,9 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
     uint64_t seg[6] = {0, 0, 0, 0, 0, 0};
     uint64_t t_last = STAMP ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
     uint32_t iters = 0;
+    // Static round-robin over the longest-first order.  (Claiming samples from a global counter, as
+    // encode4_kernel does per row, gained nothing here on 64 KiB samples and cost 2-5x on corpora of
+    // short samples: one atomic per sample on one address serialises the waves.)
     for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
         const uint64_t beg = first_u64(P.offs[s]);
@@ -796,7 +813,7 @@ hipError_t encode_max_blocks_per_cu(uint32_t lm, int* out) {
 
 // four-samples-per-wave path (max token length <= 16): one block per CU
 typedef void (*encode4_fn)(EncodeParams);
-static encode4_fn pick_encode4(bool dropout, int ppl, bool stamp = false) {
+static encode4_fn pick_encode4(bool dropout, int ppl, bool stamp) {
     if (stamp) return encode4_kernel<false, 1, true>;
     if (ppl == 1) return dropout ? encode4_kernel<true, 1, false> : encode4_kernel<false, 1, false>;
     if (ppl == 2) return dropout ? encode4_kernel<true, 2, false> : encode4_kernel<false, 2, false>;
@@ -804,19 +821,12 @@ static encode4_fn pick_encode4(bool dropout, int ppl, bool stamp = false) {
 }
 uint32_t encode4_group_bytes() { return kRows4GroupBytes; }
 uint32_t encode4_lds_bytes(int waves, int ppl) { return (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes; }
-hipError_t encode4_prepare(bool dropout, int ppl) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(pick_encode4(dropout, ppl)),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
-    if (p.stamps) {
-        encode4_fn fn = pick_encode4(false, 1, true);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), encode4_lds_bytes(waves, 1), stream, p);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(pick_encode4(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * (uint32_t)waves),
-                       encode4_lds_bytes(waves, ppl), stream, p);
+    const bool stamp = p.stamps != nullptr;
+    encode4_fn fn = pick_encode4(p.dropout > 0.0, ppl, stamp);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), encode4_lds_bytes(waves, stamp ? 1 : ppl), stream, p);
     return hipGetLastError();
 }
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {

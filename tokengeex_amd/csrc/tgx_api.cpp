@@ -243,6 +243,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     p.tokhash = m->d_tokhash;
     p.tokhash_mask = m->tokhash.mask;
     p.err_sample = m->d_ctrl + 1;
+    p.queue = m->d_ctrl;
     p.dropout = dropout;
     p.seed = seed;
     {
@@ -260,7 +261,9 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     if (use4) {
         // `bpc` blocks per CU of `waves` waves each (8 KiB of LDS per wave and position group).
         // TGX_PPL (positions per lane: 1, 2, 4), TGX_WAVES, TGX_BPC override the defaults.
-        int ppl = 1, waves = 4, bpc = 5;
+        // Two blocks of ten waves per CU (20 x 8 KiB of LDS); rows claim samples dynamically, so the
+        // geometry only has to fill the CU.
+        int ppl = 1, waves = 10, bpc = 2;
         if (const char* e = getenv("TGX_PPL")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) ppl = v;
@@ -273,7 +276,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             const int v = atoi(e);
             if (v >= 1 && v <= 8) bpc = v;
         }
-        while (waves > 1 && (uint32_t)(waves * ppl) * tgx::encode4_group_bytes() > (160u * 1024u) / (uint32_t)bpc) waves--;
+        while (waves > 1 && tgx::encode4_lds_bytes(waves, ppl) > (160u * 1024u) / (uint32_t)bpc) waves--;
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
             1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
@@ -450,8 +453,6 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
         HIP_TRY_M(tgx::encode_max_blocks_per_cu(m->lm, &occ));
         m->blocks_per_cu = std::max(1, std::min(occ, 16));
     }
-    for (int d = 0; d < 2; d++)
-        for (int q = 0; q < 3; q++) HIP_TRY_M(tgx::encode4_prepare(d == 1, 1 << q));
     HIP_TRY_M(hipStreamSynchronize(m->stream));
 #undef HIP_TRY_M
     *out = m;
@@ -967,6 +968,10 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     p.n_replicas = n_rep;
     p.logz_sum = d_z;
     p.err_snip = m->d_ctrl + 1;
+    p.queue_fwd = m->d_ctrl + 3;
+    p.queue_bwd = m->d_ctrl + 4;
+    if (hipMemsetAsync(m->d_ctrl + 3, 0x00, 16, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "E-step queue reset failed"));
     p.dropout = dropout;
     p.seed = seed;
     time_begin(m, "estep4_fwd_kernel");

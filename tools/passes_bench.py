@@ -7,8 +7,16 @@ import tokengeex_amd as tgx
 from oracle import oracle as orc
 from tokengeex_amd import synth
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
-toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
+V = int(sys.argv[2]) if len(sys.argv) > 2 else 32000
+cpu_mib = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cache", f"vocab_{V}.npz")
+if os.path.exists(cache):  # tools/make_vocab_cache.py
+    z = np.load(cache)
+    o = z["offs"].astype(np.int64); fb = z["flat"].tobytes()
+    toks, scores = [fb[o[i]:o[i + 1]] for i in range(o.size - 1)], z["scores"]
+else:
+    vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
+    toks, scores = synth.build_vocab(vflat[: 2 << 20], V, 16)
 flat, offs = synth.make_corpus(size << 20, "mixed", seed_offset=1000)
 m = tgx.NativeModel(toks, scores); c = tgx.NativeCorpus(flat, offs)
 cores = len(os.sched_getaffinity(0))
@@ -29,7 +37,7 @@ out["count_tokens"] = {"wall_ms": dt * 1e3, "kernel_ms": m.last_kernel_times(), 
 dt, (keys, counts) = timed(lambda: m.count_pairs(c))
 out["count_pairs"] = {"wall_ms": dt * 1e3, "kernel_ms": m.last_kernel_times(), "GB_per_s": flat.size / dt / 1e9, "distinct_pairs": int(keys.size)}
 # CPU oracle on a bounded prefix (all host cores) + parity
-k = int(np.searchsorted(offs, min(flat.size, 64 << 20))); sf, so = flat[: int(offs[k])], offs[: k + 1]
+k = int(np.searchsorted(offs, min(flat.size, cpu_mib << 20))); sf, so = flat[: int(offs[k])], offs[: k + 1]
 ora = orc.OracleModel(toks, scores)
 t = time.perf_counter(); st, wexp, wz, _ = ora.estep_flat(sf, so, threads=cores); dt = time.perf_counter() - t
 cs = tgx.NativeCorpus(sf, so); gexp, gz = m.estep(cs)
