@@ -139,3 +139,27 @@ def test_tokenizer_json_roundtrip_and_queries(tmp_path):
         tgx.Tokenizer.from_str('{"version":"2.0","vocab":[],"bogus":1}')
     with pytest.raises(tgx.TokenGeeXError):
         tgx.Tokenizer.from_file(str(tmp_path / "missing.json"))
+
+
+def test_tok_hash_table_is_exact_on_vocabularies():
+    """The bytes -> id table of the trace kernel (32-bit-multiply hash, csrc/trie_build.h) must map every
+    token back to its id: checked on a synthetic 6 K vocabulary, on adversarial near-duplicates, and on the
+    cached 500 K vocabulary when tools/make_vocab_cache.py has been run."""
+    import os
+    import numpy as np
+    from tokengeex_amd import _lib, synth
+    flat, _ = synth.make_corpus(1 << 20, seed_offset=5)
+    toks, _ = synth.build_vocab(flat, 6000, 16)
+    assert _lib.tok_hash_selftest(toks)[1] == 0
+    # every 1- and 2-byte string, zero bytes, duplicates (the later id must win), 16-byte tokens
+    adv = [bytes([a]) for a in range(256)] + [bytes([a, b]) for a in range(0, 256, 3) for b in range(256)]
+    adv += [b"\x00" * k for k in range(1, 17)] + [b"ab", b"ab", b"abcdefghijklmnop", b"abcdefghijklmnoq"]
+    assert _lib.tok_hash_selftest(adv)[1] == 0
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cache", "vocab_500000.npz")
+    if os.path.exists(cache):
+        z = np.load(cache)
+        o = z["offs"].astype(np.int64); fb = z["flat"].tobytes()
+        big = [fb[o[i]:o[i + 1]] for i in range(o.size - 1)]
+        assert _lib.tok_hash_selftest(big)[1] == 0
+    with pytest.raises(_lib.TokenGeeXError):
+        _lib.tok_hash_selftest([b"x" * 17])

@@ -40,6 +40,7 @@ SYMBOLS = {
     "tgx_flat_trie_search": (_u64, [_vp, _vp, _u64, _vp, _vp, _u64]),
     "tgx_flat_trie_stats": (None, [_vp, _pu64, _pu64, C.POINTER(C.c_uint32)]),
     "tgx_flat_trie_copy": (None, [_vp, _vp, _vp, _vp]),
+    "tgx_tok_hash_selftest": (_i, [_vp, _vp, _u32, C.POINTER(C.c_uint32), _pu64]),
     "tgx_dropout_u01_host": (_d, [_u64, _u64, _u64, _u32]),
     "tgx_encode_batch": (_i, [_vp, _vp, _vp, _u64, _d, _u64, _pvp]),
     "tgx_result_num_samples": (_u64, [_vp]),
@@ -344,6 +345,14 @@ class FlatTrie:
         ids = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(k, 1),))[:k].copy()
         lib.tgx_free(p)
         return always_keep, alt_offs, ids
+
+
+def tok_hash_selftest(tokens: list[bytes]) -> tuple[int, int]:
+    """-> (seed, mismatches) of the bytes -> id table built for `tokens` (host only)."""
+    flat, offs = pack(tokens)
+    seed, bad = C.c_uint32(), C.c_uint64()
+    check(lib.tgx_tok_hash_selftest(ptr(flat) if flat.size else None, ptr(offs), len(tokens), C.byref(seed), C.byref(bad)))
+    return seed.value, bad.value
 
 
 def digamma(x: float) -> float:

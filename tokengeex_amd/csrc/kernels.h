@@ -22,6 +22,7 @@ struct EncodeParams {
     uint8_t* bp8;                   // u8[N] rows4 back-pointers: len - 1, 0xFF = unreachable
     const void* tokhash;            // TokHashEntry[mask + 1]: token bytes -> id (rows4 trace)
     uint32_t tokhash_mask;
+    uint32_t tokhash_seed;
     unsigned long long* err_sample; // min failing sample (init ~0)
     unsigned long long* queue;      // rows4: next unclaimed position of `order` (init 0)
     double dropout;

@@ -589,13 +589,21 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
 }
 
 // same function as tgx::tok_hash64 (trie_build.h)
-__device__ __forceinline__ uint64_t tok_hash64_dev(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t len) {
-    uint64_t h = (((uint64_t)w1 << 32) | w0) * 0x9E3779B97F4A7C15ULL;
-    h ^= ((((uint64_t)w3 << 32) | w2) + len) * 0xC2B2AE3D27D4EB4FULL;
-    h ^= h >> 29;
-    h *= 0xBF58476D1CE4E5B9ULL;
-    h ^= h >> 32;
-    return h;
+__device__ __forceinline__ uint32_t rotl32_dev(uint32_t x, int r) { return __builtin_rotateleft32(x, (uint32_t)r); }
+__device__ __forceinline__ uint64_t tok_hash64_dev(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t len, uint32_t seed) {
+    uint32_t a = (w0 ^ (len << 27) ^ seed) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    uint32_t b = a;
+    a = (a + w1) * 0xC2B2AE35u;
+    a ^= a >> 13;
+    b = rotl32_dev(b, 11) ^ a;
+    a = (a + w2) * 0x27D4EB2Fu;
+    a ^= a >> 16;
+    b = rotl32_dev(b, 11) ^ a;
+    a = (a + w3) * 0x165667B1u;
+    a ^= a >> 15;
+    b = rotl32_dev(b, 11) + (w0 ^ rotl32_dev(w1, 8) ^ rotl32_dev(w2, 16) ^ rotl32_dev(w3, 24));
+    return ((uint64_t)b << 32) | a;
 }
 
 // Back-trace + id emission for the rows4 path: one wave per sample, 1-byte back-pointers
@@ -647,6 +655,9 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
             TGX_STAMP(1)  // window loads issued / consumed
             uint64_t ends = 0;
             int32_t qq = (int32_t)((uint32_t)q - wq);
+            // (Tried without gain: the 64 back-pointers packed into four 64-bit scalars for a pure-SALU hop
+            // chain, 6.4 ms against 5.9 ms per GiB; issuing this window's table probes before the NEXT
+            // window's hop chain — software pipelining — 6.5 ms.)
             while (qq >= 0) {  // model.rs:113-126, 64 positions per load
                 const uint32_t hh = readlane_u32(h, (uint32_t)qq);
                 ends |= 1ULL << qq;
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
                     const uint32_t nb = len > 4u * j ? len - 4u * j : 0u;  // bytes of the token in this dword
                     b[j] = nb >= 4u ? v : (v & ((1u << (8u * nb)) - 1u));
                 }
-                const uint64_t hk = tok_hash64_dev(b[0], b[1], b[2], b[3], len);
+                const uint64_t hk = tok_hash64_dev(b[0], b[1], b[2], b[3], len, P.tokhash_seed);
                 uint32_t slot = (uint32_t)hk & P.tokhash_mask;
                 uint32_t id = 0;
                 bool found = false;

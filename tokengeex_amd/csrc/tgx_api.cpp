@@ -135,7 +135,7 @@ struct tgx_model {
 
 struct tgx_corpus {
     int device = 0;
-    uint64_t n_samples = 0, n_bytes = 0;
+    uint64_t n_samples = 0, n_bytes = 0, max_len = 0;  // max_len: longest sample in bytes
     std::vector<uint64_t> h_offs;
     uint8_t* d_text = nullptr;        // = d_text_alloc + 256 (the backward E-step sweep reads before a position)
     uint8_t* d_text_alloc = nullptr;
@@ -242,6 +242,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     p.bp8 = reinterpret_cast<uint8_t*>(c->d_bp);  // the rows4 path uses the scratch row as bytes
     p.tokhash = m->d_tokhash;
     p.tokhash_mask = m->tokhash.mask;
+    p.tokhash_seed = m->tokhash.seed;
     p.err_sample = m->d_ctrl + 1;
     p.queue = m->d_ctrl;
     p.dropout = dropout;
@@ -264,6 +265,23 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         // Two blocks of ten waves per CU (20 x 8 KiB of LDS); rows claim samples dynamically, so the
         // geometry only has to fill the CU.
         int ppl = 1, waves = 10, bpc = 2;
+        {
+            // Positions per lane.  A sample is a serial chain of 16 * ppl positions per trip, so the
+            // longest sample bounds the pass from below, while more positions per lane cost LDS and with
+            // it waves per CU.  Measured on 1 x MI355X (tools/ppl_sweep.py): throughput 60 / 50 / 34 GB/s
+            // and 13.5 / 10.7 / 9.1 ms per 64 KiB of chain for ppl = 1 / 2 / 4; take the smallest estimate.
+            const double gbps[3] = {60.0, 50.0, 34.0}, chain_ms[3] = {13.5, 10.7, 9.1};
+            double best_t = 0;
+            for (int i = 0; i < 3; i++) {
+                const double t = std::max((double)c->n_bytes / (gbps[i] * 1e6), (double)c->max_len / 65536.0 * chain_ms[i]);
+                if (i == 0 || t < best_t * 0.95) {  // switch only for a clear gain
+                    best_t = t;
+                    ppl = 1 << i;
+                }
+            }
+            if (ppl == 2) { waves = 5; bpc = 2; }
+            if (ppl == 4) { waves = 5; bpc = 1; }
+        }
         if (const char* e = getenv("TGX_PPL")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) ppl = v;
@@ -518,6 +536,38 @@ void tgx_flat_trie_stats(const tgx_flat_trie* t, uint64_t* n_slots, uint64_t* n_
     if (n_nodes) *n_nodes = t->flat.n_nodes;
     if (max_token_len) *max_token_len = t->flat.max_token_len;
 }
+tgx_status tgx_tok_hash_selftest(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, uint32_t* seed,
+                                 uint64_t* mismatches) {
+    if (!offs || !mismatches) return TGX_ERR_INVALID;
+    tgx::TokHashTable t;
+    tgx::build_tok_hash(bytes, offs, vocab_size, &t);
+    if (!t.ok) return TGX_ERR_UNSUPPORTED;
+    if (seed) *seed = t.seed;
+    // the id a lookup must give: the LAST vocabulary entry with these bytes (src/trie.rs:19)
+    uint64_t bad = 0;
+    for (uint32_t id = 0; id < vocab_size; id++) {
+        const uint32_t len = (uint32_t)(offs[id + 1] - offs[id]);
+        if (len == 0) continue;
+        uint32_t w[4] = {0, 0, 0, 0};
+        memcpy(w, bytes + offs[id], len);
+        const uint64_t h = tgx::tok_hash64(w[0], w[1], w[2], w[3], len, t.seed);
+        uint32_t i = (uint32_t)h & t.mask;
+        bool found = false;
+        for (uint32_t probe = 0; probe <= t.mask; probe++) {  // the device loop of trace_kernel
+            const tgx::TokHashEntry& e = t.slots[i];
+            if (!e.used) break;
+            if (e.hash == h) {
+                const uint32_t o = e.id;
+                found = offs[o + 1] - offs[o] == len && memcmp(bytes + offs[o], bytes + offs[id], len) == 0 && o >= id;
+                break;
+            }
+            i = (i + 1) & t.mask;
+        }
+        if (!found) bad++;
+    }
+    *mismatches = bad;
+    return TGX_OK;
+}
 void tgx_flat_trie_copy(const tgx_flat_trie* t, uint32_t* check, uint32_t* base_flags, uint32_t* tokid) {
     if (!t) return;
     for (size_t i = 0; i < t->flat.table.size(); i++) {
@@ -567,6 +617,7 @@ tgx_status tgx_corpus_upload(int device, const uint8_t* text, const uint64_t* of
         return ho[a + 1] - ho[a] > ho[b + 1] - ho[b];
     });
 
+    c->max_len = n_samples ? ho[order[0] + 1] - ho[order[0]] : 0;
     auto cleanup = [&](tgx_status st) {
         tgx_corpus_free(c);
         return st;

@@ -217,23 +217,15 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     out->n_nodes = n_nodes;
 }
 
-void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out) {
-    uint32_t cap = 1024;
-    while (cap < vocab_size * 8u) cap <<= 1;  // load factor <= 1/8: a probe chain is as long as its slowest lane
-    out->slots.assign(cap, TokHashEntry{0, 0, 0});
-    out->mask = cap - 1;
-    out->ok = true;
+static bool fill_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out) {
+    std::fill(out->slots.begin(), out->slots.end(), TokHashEntry{0, 0, 0});
     for (uint32_t id = 0; id < vocab_size; id++) {
         const uint64_t b = offs[id], e = offs[id + 1];
         const uint32_t len = (uint32_t)(e - b);
         if (len == 0) continue;  // never matched
-        if (len > 16) {
-            out->ok = false;
-            return;
-        }
         uint32_t w[4] = {0, 0, 0, 0};
         std::memcpy(w, bytes + b, len);
-        const uint64_t h = tok_hash64(w[0], w[1], w[2], w[3], len);
+        const uint64_t h = tok_hash64(w[0], w[1], w[2], w[3], len, out->seed);
         uint32_t i = (uint32_t)h & out->mask;
         for (;;) {
             TokHashEntry& s = out->slots[i];
@@ -244,15 +236,27 @@ void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_s
             if (s.hash == h) {
                 // same hash: must be the same bytes (a duplicate token: the later id wins, trie.rs:19)
                 const uint64_t ob = offs[s.id], oe = offs[s.id + 1];
-                if (oe - ob != e - b || std::memcmp(bytes + ob, bytes + b, len) != 0) {
-                    out->ok = false;  // a genuine 64-bit collision: keep trie handles
-                    return;
-                }
+                if (oe - ob != e - b || std::memcmp(bytes + ob, bytes + b, len) != 0) return false;  // a genuine collision
                 s.id = id;
                 break;
             }
             i = (i + 1) & out->mask;
         }
+    }
+    return true;
+}
+
+void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out) {
+    uint32_t cap = 1024;
+    while (cap < vocab_size * 8u) cap <<= 1;  // load factor <= 1/8: a probe chain is as long as its slowest lane
+    out->slots.assign(cap, TokHashEntry{0, 0, 0});
+    out->mask = cap - 1;
+    out->ok = false;
+    for (uint32_t id = 0; id < vocab_size; id++)
+        if (offs[id + 1] - offs[id] > 16) return;  // longer tokens: callers keep trie handles
+    for (uint32_t attempt = 0; attempt < 8 && !out->ok; attempt++) {
+        out->seed = attempt * 0x9E3779B1u;
+        out->ok = fill_tok_hash(bytes, offs, vocab_size, out);
     }
 }
 

@@ -54,16 +54,29 @@ struct TokHashEntry {
 struct TokHashTable {
     std::vector<TokHashEntry> slots;
     uint32_t mask = 0;
+    uint32_t seed = 0;
     bool ok = false;
 };
-// hash of a token of len (1..16) bytes given as four little-endian zero-padded dwords
-inline uint64_t tok_hash64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t len) {
-    uint64_t h = (((uint64_t)w1 << 32) | w0) * 0x9E3779B97F4A7C15ULL;
-    h ^= ((((uint64_t)w3 << 32) | w2) + len) * 0xC2B2AE3D27D4EB4FULL;
-    h ^= h >> 29;
-    h *= 0xBF58476D1CE4E5B9ULL;
-    h ^= h >> 32;
-    return h;
+// Hash of a token of len (1..16) bytes given as four little-endian zero-padded dwords: two 32-bit
+// words.  `lo` (slot index and half of the tag) is a multiply-xorshift chain over the dwords, `hi` folds
+// the chain's intermediate states with the raw dwords.  32-bit multiplies only: the trace kernel is
+// bound by VALU issue and 64-bit multiplies run at a quarter of the rate four times over.  It only has to
+// be injective on the vocabulary, which build_tok_hash verifies (another seed is tried otherwise).
+inline uint32_t tok_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+inline uint64_t tok_hash64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t len, uint32_t seed) {
+    uint32_t a = (w0 ^ (len << 27) ^ seed) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    uint32_t b = a;
+    a = (a + w1) * 0xC2B2AE35u;
+    a ^= a >> 13;
+    b = tok_rotl32(b, 11) ^ a;
+    a = (a + w2) * 0x27D4EB2Fu;
+    a ^= a >> 16;
+    b = tok_rotl32(b, 11) ^ a;
+    a = (a + w3) * 0x165667B1u;
+    a ^= a >> 15;
+    b = tok_rotl32(b, 11) + (w0 ^ tok_rotl32(w1, 8) ^ tok_rotl32(w2, 16) ^ tok_rotl32(w3, 24));
+    return ((uint64_t)b << 32) | a;
 }
 void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out);
 

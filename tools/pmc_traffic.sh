@@ -1,0 +1,32 @@
+#!/bin/bash
+# HBM traffic of the bench kernels: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md),
+# --pmc with --kernel-trace only.  usage: tools/pmc_traffic.sh <outdir-under-gpurun_out>
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/$1
+mkdir -p $OUT
+cd /tmp
+for P in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 200 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/$P -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/$P.log 2>&1 || { echo "$P failed: stopping"; exit 1; }
+done
+python3 - $OUT <<'PY'
+import csv, glob, collections, json, sys
+out = sys.argv[1]
+res = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for d in glob.glob(f"{out}/{c}/*/*_counter_collection.csv"):
+        with open(d) as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != c: continue
+                k = row["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
+                agg[k] += float(row["Counter_Value"]); cnt[k] += 1
+    for k, v in agg.items():
+        res[k][c + "_KB_per_launch"] = v / cnt[k]
+# gfx950: FETCH_SIZE reports half of the bytes of wide coalesced reads (guide); WRITE_SIZE is exact for
+# 16-B-per-lane stores, partial lines are counted as whole requests
+for k, v in res.items():
+    v["hbm_bytes_per_launch_corrected"] = 2 * 1024 * v.get("FETCH_SIZE_KB_per_launch", 0) + 1024 * v.get("WRITE_SIZE_KB_per_launch", 0)
+json.dump({k: v for k, v in res.items() if k.startswith(("encode", "trace", "compact", "scan"))}, open(out + "/traffic.json", "w"), indent=1)
+print(open(out + "/traffic.json").read())
+PY
