@@ -113,6 +113,15 @@ def main() -> None:
         dom = max(kernel_ms, key=kernel_ms.get) if kernel_ms else "encode_kernel"
         dom_ms = kernel_ms.get(dom, 0.0) / steps
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the PMC passes of this workload
+        # (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, gfx950 x2 fetch
+        # correction); counters cannot be read from inside this process, so the committed figure of the
+        # last profiled run is reported, and only for the workload it was taken on
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "f_final_pmc_traffic.json")
+        if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length) == (1024, 32000, "mixed", 16):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dom.split("<")[0], {}).get("hbm_bytes_per_launch_corrected")
         out = {
             "metric": "MB/s raw bytes encoded (and tokens/s) at 32K/64K vocab, 1/2/4/8 GPUs",
             "value": round(mb_s, 2),
@@ -137,7 +146,7 @@ def main() -> None:
             "kernel_ms_per_step": {k: round(v / steps, 3) for k, v in kernel_ms.items()},
             "setup_s": round(setup_s, 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
         if not args.no_cpu_baseline:
