@@ -114,8 +114,8 @@ uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int* out);
 hipError_t launch_encode(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 uint32_t encode4_group_bytes();
-hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream);
-uint32_t encode4_lds_bytes(int waves, int ppl);
+hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream);
+uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);
 hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);

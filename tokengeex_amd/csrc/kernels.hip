@@ -374,7 +374,9 @@ constexpr uint32_t kRows4GroupBytes = kRows4Entries * 8u;  // 8192
         t_last = _now;                                                 \
     }
 
-template <bool DROPOUT, int PPL, bool STAMP>
+// ROOT: the 256 records of the root's children (one 4 KiB block of the double array) are copied into
+// the block's LDS, and the first step of every walk — always a full 64-lane gather — reads them there.
+template <bool DROPOUT, int PPL, bool STAMP, bool ROOT>
 __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
@@ -387,7 +389,13 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     // block and shared by one 16-wave block per CU, and lost both times: 21.2 ms against 19.7 ms at 1 GiB.
     // A walk step still waits for its slowest lane, which goes to L2, and pays an extra LDS read and a
     // select; the LDS pipe is as loaded as the gather path.)
-    unsigned char* wbase = smem + (size_t)wave * (PPL * kRows4GroupBytes);
+    const uint4* rootc = reinterpret_cast<const uint4*>(smem);
+    unsigned char* wbase = smem + (ROOT ? 4096u : 0u) + (size_t)wave * (PPL * kRows4GroupBytes);
+    if (ROOT) {
+        uint4* rw = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(P.root_base & ~255u) + i];
+        __syncthreads();
+    }
     const uint32_t wpb = blockDim.x >> 6;
 
     // per-row state (identical in the 16 lanes of a row)
@@ -491,10 +499,14 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
                 for (int g = 0; g < PPL; ++g) {
                     const uint32_t c = (bytes[g][d >> 2] >> ((d & 3) * 8)) & 0xFFu;
                     t[g] = alive[g] ? (base[g] ^ c) : 0u;
-                    rec[g] = trie[t[g]];
+                    if (ROOT && d == 0)
+                        rec[g] = rootc[(P.root_base ^ c) & 255u];  // idle lanes read a valid entry too; `alive` masks it
+                    else
+                        rec[g] = trie[t[g]];
                 }
 #pragma unroll
-                for (int g = 0; g < PPL; ++g) asm volatile("" : "+v"(rec[g].x), "+v"(rec[g].y), "+v"(rec[g].z), "+v"(rec[g].w));
+                for (int g = 0; g < PPL; ++g)
+                    if (!(ROOT && d == 0)) asm volatile("" : "+v"(rec[g].x), "+v"(rec[g].y), "+v"(rec[g].z), "+v"(rec[g].w));
 #pragma unroll
                 for (int g = 0; g < PPL; ++g) {
                     alive[g] = alive[g] && rec[g].x == cur[g];
@@ -824,20 +836,25 @@ hipError_t encode_max_blocks_per_cu(uint32_t lm, int* out) {
 
 // four-samples-per-wave path (max token length <= 16): one block per CU
 typedef void (*encode4_fn)(EncodeParams);
-static encode4_fn pick_encode4(bool dropout, int ppl, bool stamp) {
-    if (stamp) return encode4_kernel<false, 1, true>;
-    if (ppl == 1) return dropout ? encode4_kernel<true, 1, false> : encode4_kernel<false, 1, false>;
-    if (ppl == 2) return dropout ? encode4_kernel<true, 2, false> : encode4_kernel<false, 2, false>;
-    return dropout ? encode4_kernel<true, 4, false> : encode4_kernel<false, 4, false>;
+static encode4_fn pick_encode4(bool dropout, int ppl, bool stamp, bool root) {
+    if (stamp) return encode4_kernel<false, 1, true, false>;
+    if (root) return dropout ? encode4_kernel<true, 1, false, true> : encode4_kernel<false, 1, false, true>;
+    if (ppl == 1) return dropout ? encode4_kernel<true, 1, false, false> : encode4_kernel<false, 1, false, false>;
+    if (ppl == 2) return dropout ? encode4_kernel<true, 2, false, false> : encode4_kernel<false, 2, false, false>;
+    return dropout ? encode4_kernel<true, 4, false, false> : encode4_kernel<false, 4, false, false>;
 }
 uint32_t encode4_group_bytes() { return kRows4GroupBytes; }
-uint32_t encode4_lds_bytes(int waves, int ppl) { return (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes; }
-hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
+uint32_t encode4_lds_bytes(int waves, int ppl, bool root) {
+    return (root ? 4096u : 0u) + (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes;
+}
+// root = true (first trie level in LDS) exists for ppl == 1 only
+hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream) {
     const bool stamp = p.stamps != nullptr;
-    encode4_fn fn = pick_encode4(p.dropout > 0.0, ppl, stamp);
+    root = root && !stamp && ppl == 1;
+    encode4_fn fn = pick_encode4(p.dropout > 0.0, ppl, stamp, root);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), encode4_lds_bytes(waves, stamp ? 1 : ppl), stream, p);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), encode4_lds_bytes(waves, stamp ? 1 : ppl, root), stream, p);
     return hipGetLastError();
 }
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {

@@ -294,7 +294,9 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             const int v = atoi(e);
             if (v >= 1 && v <= 8) bpc = v;
         }
-        while (waves > 1 && tgx::encode4_lds_bytes(waves, ppl) > (160u * 1024u) / (uint32_t)bpc) waves--;
+        bool root = ppl == 1;  // first trie level in LDS (4 KiB per block)
+        if (const char* e = getenv("TGX_ROOT")) root = root && atoi(e) != 0;
+        while (waves > 1 && tgx::encode4_lds_bytes(waves, ppl, root) > (160u * 1024u) / (uint32_t)bpc) waves--;
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
             1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
@@ -308,7 +310,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             }
         }
         time_begin(m, "encode4_kernel");
-        HIP_TRY(tgx::launch_encode4(p, ppl, waves, blocks4, m->stream));
+        HIP_TRY(tgx::launch_encode4(p, ppl, waves, blocks4, root, m->stream));
         time_end(m);
         if (d_stamps) {  // diagnostic: mean cycles per iteration and phase over all waves
             std::vector<unsigned long long> h(n_stamp_waves * 8);
