@@ -22,3 +22,62 @@ def assert_same_encoding(native_model, oracle_model, flat, offs, dropout=0.0, se
     np.testing.assert_array_equal(got_offs, want_offs)
     np.testing.assert_array_equal(got_ids, want_ids)
     return got_ids, got_offs
+
+
+def estep_longdouble(oracle_model, text: bytes):
+    """Expected counts and log z of ONE snippet in 80-bit extended precision (64-bit mantissa), in the linear
+    domain with per-position power-of-two exponents: alpha_true[p] = am[p] * 2**ae[p].  Independent of both
+    the oracle's and the kernels' arithmetic; rounding ~1e-19 per operation, so it serves as the truth that
+    two f64 evaluations are measured against (tests of the E-step tolerance)."""
+    ld = np.longdouble
+    n = len(text)
+    V = oracle_model.vocab_size
+    w = np.exp(np.asarray(oracle_model.scores, dtype=ld))
+    matches = [oracle_model.common_prefix_search(text[p:p + 64]) for p in range(n)]  # [(id, len)] per start
+
+    def sweep(edges_from):
+        """edges_from(x) -> [(id, target)] for source x in sweep order; returns (mantissas, exponents)."""
+        m = [ld(0)] * (n + 1)
+        e = [0] * (n + 1)
+        started = [False] * (n + 1)
+        return m, e, started
+
+    # forward
+    am, ae, st = sweep(None)
+    am[0], st[0] = ld(1), True
+    for p in range(n):
+        if not st[p]:
+            raise ValueError("position without incoming token")
+        mm, ee = np.frexp(am[p])
+        am[p], ae[p] = mm, ae[p] + int(ee)
+        for tid, ln in matches[p]:
+            t = p + ln
+            term = am[p] * w[tid]
+            if not st[t]:
+                am[t], ae[t], st[t] = term, ae[p], True
+            else:
+                am[t] = am[t] + np.ldexp(term, ae[p] - ae[t])
+    mm, ee = np.frexp(am[n])
+    am[n], ae[n] = mm, ae[n] + int(ee)
+    logz = float(np.log(am[n]) + ld(ae[n]) * np.log(ld(2)))
+    # backward
+    bm = [ld(0)] * (n + 1)
+    be = [0] * (n + 1)
+    bs = [False] * (n + 1)
+    bm[n], bs[n] = ld(1), True
+    ends = [[] for _ in range(n + 1)]
+    for p in range(n):
+        for tid, ln in matches[p]:
+            ends[p + ln].append((tid, p))
+    expected = np.zeros(V, dtype=ld)
+    for q in range(n, 0, -1):
+        mm, ee = np.frexp(bm[q])
+        bm[q], be[q] = mm, be[q] + int(ee)
+        for tid, p in ends[q]:
+            term = bm[q] * w[tid]
+            expected[tid] += np.ldexp(am[p] * term / am[n], ae[p] + be[q] - ae[n])
+            if not bs[p]:
+                bm[p], be[p], bs[p] = term, be[q], True
+            else:
+                bm[p] = bm[p] + np.ldexp(term, be[q] - be[p])
+    return expected.astype(np.float64), logz

@@ -89,10 +89,14 @@ struct Estep4Params {
     uint32_t root_fwd, root_rev;
     double* alpha;                  // f64[N + K + pad]: snippet k's A[0..n] at soffs[k] + k
     double* zarr;                   // f64[K] z = A[n] per snippet
+    int32_t* alpha_exp;             // linear-domain kernels (estep4l.hip): power-of-two exponent of each block of 16
+                                    // alpha values, snippet k's blocks at (soffs[k] >> 4) + k
     double* expected_slot;          // f64[n_replicas][n_slots_rev]
     uint32_t n_slots_rev, n_replicas;
     double* logz_sum;
     unsigned long long* err_snip;   // min snippet whose z is not normal (init ~0)
+    uint32_t flags;                 // timing experiments only (TGX_FLAGS with TGX_DEBUG=1): 8 = no cold-slot atomics
+    unsigned long long* range_flag; // linear-domain forward kernel: set when the pass needs the log-domain kernels (init 0)
     unsigned long long* queue_fwd;  // next unclaimed position of `order`, forward / backward kernel (init 0)
     unsigned long long* queue_bwd;
     double dropout;
@@ -101,6 +105,9 @@ struct Estep4Params {
 hipError_t estep4_prepare();
 hipError_t launch_estep4_fwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
 hipError_t launch_estep4_bwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
+hipError_t estep4l_prepare();
+hipError_t launch_estep4l_fwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
+hipError_t launch_estep4l_bwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
 hipError_t launch_estep4_reduce(const double* rep, double* out, uint32_t n_slots, uint32_t n_replicas,
                                 hipStream_t stream);
 

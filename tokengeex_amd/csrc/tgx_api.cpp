@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -124,6 +125,9 @@ struct tgx_model {
     std::vector<double> vocab_scores;
     tgx::FlatTrie flat_rev;
     void* d_trie_rev = nullptr;
+    void* d_trie_w = nullptr;       // forward / reversed tables with w = exp(score) in place of the score
+    void* d_trie_rev_w = nullptr;   //   (linear-domain E-step, estep4l.hip)
+    bool estep_linear_ok = false;   // tables for the linear-domain E-step kernels exist
     tgx::TokHashTable tokhash;      // token bytes -> id (rows4 trace); ok == false: not usable
     void* d_tokhash = nullptr;
     int estep_blocks_per_cu = 0;
@@ -489,6 +493,8 @@ void tgx_model_destroy(tgx_model* m) {
     }
     if (m->d_trie) (void)hipFree(m->d_trie);
     if (m->d_trie_rev) (void)hipFree(m->d_trie_rev);
+    if (m->d_trie_w) (void)hipFree(m->d_trie_w);
+    if (m->d_trie_rev_w) (void)hipFree(m->d_trie_rev_w);
     if (m->d_tokhash) (void)hipFree(m->d_tokhash);
     if (m->d_tokid) (void)hipFree(m->d_tokid);
     if (m->d_ctrl) (void)hipFree(m->d_ctrl);
@@ -936,6 +942,31 @@ static tgx_status ensure_reverse_trie(tgx_model* m) {
     HIP_TRY(tgx::estep_max_blocks_per_cu(m->lm, &occ));
     m->estep_blocks_per_cu = std::max(1, std::min(occ, 16));
     HIP_TRY(tgx::estep4_prepare());
+    // Linear-domain E-step (estep4l.hip): its tables carry w = exp(score).  Whether a pass can use it
+    // (every position has an incoming token, values stay inside the f64 range) is decided per pass by
+    // the forward kernel itself; scores beyond +-300 would overflow exp() or underflow within a block.
+    bool ok = m->lm <= 16 && m->scores_finite;
+    for (uint32_t i = 0; ok && i < V; i++) ok = m->vocab_scores[i] >= -300.0 && m->vocab_scores[i] <= 300.0;
+    if (ok) {
+        auto upload_weights = [&](const tgx::FlatTrie& ft, void** dst) -> hipError_t {
+            std::vector<tgx::TrieRec> w(ft.table);
+            for (tgx::TrieRec& r : w) {
+                double sc = 0.0, wt = 0.0;
+                if (r.base & tgx::kTerminalBit) {
+                    memcpy(&sc, &r.score_bits, 8);
+                    wt = std::exp(sc);
+                }
+                memcpy(&r.score_bits, &wt, 8);
+            }
+            hipError_t e = hipMalloc(dst, w.size() * sizeof(tgx::TrieRec));
+            if (e != hipSuccess) return e;
+            return hipMemcpy(*dst, w.data(), w.size() * sizeof(tgx::TrieRec), hipMemcpyHostToDevice);
+        };
+        HIP_TRY(upload_weights(m->flat, &m->d_trie_w));
+        HIP_TRY(upload_weights(m->flat_rev, &m->d_trie_rev_w));
+        HIP_TRY(tgx::estep4l_prepare());
+    }
+    m->estep_linear_ok = ok;
     return TGX_OK;
 }
 
@@ -973,10 +1004,16 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     const size_t abytes = (size_t)(N + K + 128) * 8, ebytes = (size_t)(n_rep + 1) * n_rev * 8 + 256, zbytes = (size_t)K * 8 + 256;
     const size_t obytes = (size_t)(K + 1) * 8 + 256, ordbytes = (size_t)K * 4 + 256;
     double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr, *d_zarr = nullptr;
+    int32_t* d_aexp = nullptr;  // block exponents of alpha (linear-domain kernels)
+    const size_t xbytes = (size_t)((N >> 4) + K + 128) * 4;
+    // TGX_ESTEP=log keeps the log-domain kernels (A/B timing, tests of both)
+    const char* force_log = getenv("TGX_ESTEP");
+    const bool linear = m->estep_linear_ok && !(force_log && strcmp(force_log, "log") == 0);
     uint64_t *d_soffs = nullptr, *d_sbase = nullptr;
     uint32_t *d_order = nullptr, *d_ssample = nullptr;
     auto cleanup = [&](tgx_status s2) {
         pool_free(m->device, d_alpha, abytes);
+        pool_free(m->device, d_aexp, xbytes);
         pool_free(m->device, d_exp, ebytes);
         pool_free(m->device, d_z, 256);
         pool_free(m->device, d_zarr, zbytes);
@@ -987,6 +1024,7 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         return s2;
     };
     if (pool_alloc(m->device, abytes, (void**)&d_alpha) != hipSuccess ||
+        (linear && pool_alloc(m->device, xbytes, (void**)&d_aexp) != hipSuccess) ||
         pool_alloc(m->device, ebytes, (void**)&d_exp) != hipSuccess ||
         pool_alloc(m->device, 256, (void**)&d_z) != hipSuccess ||
         pool_alloc(m->device, zbytes, (void**)&d_zarr) != hipSuccess ||
@@ -1010,8 +1048,9 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     p.n_snips = K;
     p.snip_sample = d_ssample;
     p.snip_base = d_sbase;
-    p.trie_fwd = m->d_trie;
-    p.trie_rev = m->d_trie_rev;
+    p.trie_fwd = linear ? m->d_trie_w : m->d_trie;
+    p.trie_rev = linear ? m->d_trie_rev_w : m->d_trie_rev;
+    p.alpha_exp = d_aexp;
     p.root_fwd = m->flat.table[0].base & ~tgx::kTerminalBit;
     p.root_rev = m->flat_rev.table[0].base & ~tgx::kTerminalBit;
     p.alpha = d_alpha;
@@ -1023,18 +1062,46 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     p.err_snip = m->d_ctrl + 1;
     p.queue_fwd = m->d_ctrl + 3;
     p.queue_bwd = m->d_ctrl + 4;
-    if (hipMemsetAsync(m->d_ctrl + 3, 0x00, 16, m->stream) != hipSuccess)
-        return cleanup(fail(TGX_ERR_DEVICE, "E-step queue reset failed"));
+    p.range_flag = m->d_ctrl + 5;
+    {
+        const char* f = debug_on() ? getenv("TGX_FLAGS") : nullptr;
+        p.flags = f ? (uint32_t)atoi(f) : 0u;
+    }
     p.dropout = dropout;
     p.seed = seed;
-    time_begin(m, "estep4_fwd_kernel");
-    if (tgx::launch_estep4_fwd(p, (uint32_t)m->num_cus, m->stream) != hipSuccess)
-        return cleanup(fail(TGX_ERR_DEVICE, "estep4 forward launch failed"));
-    time_end(m);
-    time_begin(m, "estep4_bwd_kernel");
-    if (tgx::launch_estep4_bwd(p, (uint32_t)m->num_cus, m->stream) != hipSuccess)
-        return cleanup(fail(TGX_ERR_DEVICE, "estep4 backward launch failed"));
-    time_end(m);
+    // The linear-domain kernels are tried first; if some position of some snippet has no incoming token
+    // (lattice.rs:255's 0.0 case, e.g. a byte that is no token) or a value left the f64 range, the forward
+    // kernel says so and the pass is redone with the log-domain kernels.
+    bool use_linear = linear;
+    for (;;) {
+        p.trie_fwd = use_linear ? m->d_trie_w : m->d_trie;
+        p.trie_rev = use_linear ? m->d_trie_rev_w : m->d_trie_rev;
+        if (hipMemsetAsync(m->d_ctrl + 3, 0x00, 24, m->stream) != hipSuccess ||
+            hipMemsetAsync(d_z, 0, 256, m->stream) != hipSuccess ||
+            hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "E-step queue reset failed"));
+        time_begin(m, use_linear ? "estep4l_fwd_kernel" : "estep4_fwd_kernel");
+        if ((use_linear ? tgx::launch_estep4l_fwd(p, (uint32_t)m->num_cus, m->stream)
+                        : tgx::launch_estep4_fwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "estep4 forward launch failed"));
+        time_end(m);
+        if (use_linear) {
+            unsigned long long flag = 0;
+            if (hipMemcpyAsync(&flag, m->d_ctrl + 5, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+                hipStreamSynchronize(m->stream) != hipSuccess)
+                return cleanup(fail(TGX_ERR_DEVICE, "E-step forward pass failed: %s", hipGetErrorString(hipGetLastError())));
+            if (flag != 0) {
+                use_linear = false;
+                continue;
+            }
+        }
+        time_begin(m, use_linear ? "estep4l_bwd_kernel" : "estep4_bwd_kernel");
+        if ((use_linear ? tgx::launch_estep4l_bwd(p, (uint32_t)m->num_cus, m->stream)
+                        : tgx::launch_estep4_bwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "estep4 backward launch failed"));
+        time_end(m);
+        break;
+    }
     double* d_sum = d_exp + (size_t)n_rep * n_rev;  // replica sums
     time_begin(m, "estep4_reduce_kernel");
     if (tgx::launch_estep4_reduce(d_exp, d_sum, (uint32_t)n_rev, n_rep, m->stream) != hipSuccess)
