@@ -329,6 +329,13 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
 // later ones only when strictly greater, absent tokens and unreachable sources give
 // cand = -inf and never win.  This needs every vocabulary score to be finite; models
 // with +-inf / NaN scores use the generic kernel instead.
+// rows4 back-pointer bytes live in a per-sample region of the scratch row that starts at bp8_base(beg, s)
+// and are permuted inside every group of 64 positions so that the four bytes one lane produces in four
+// consecutive trips are adjacent: a row of 16 lanes then writes one full 64-byte segment per group instead
+// of four 16-byte pieces (HBM write traffic of encode4_kernel 3.99 -> ~1.1 GB per GiB of text).
+__device__ __forceinline__ uint64_t bp8_base(uint64_t beg, uint32_t s) { return (beg + 128ull * s) & ~3ull; }
+__device__ __forceinline__ uint32_t bp8_perm(uint32_t j) { return (j & ~63u) | ((j & 15u) << 2) | ((j >> 4) & 3u); }
+
 constexpr uint32_t kNoStep = 0xFFu;  // "nothing pushed into this accumulator yet"
 
 // The winner is remembered as the step U that pushed it; with the lane's own index that
@@ -376,8 +383,11 @@ constexpr uint32_t kRows4GroupBytes = kRows4Entries * 8u;  // 8192
 
 // ROOT: the 256 records of the root's children (one 4 KiB block of the double array) are copied into
 // the block's LDS, and the first step of every walk — always a full 64-lane gather — reads them there.
+// launch_bounds(.., 6 waves per SIMD) for PPL = 1: at most 80 VGPRs.  Two blocks of ten waves put SIX waves on some SIMD; with 81+
+// registers (which the compiler picks on small source changes: launch_bounds(1024) alone allows 128) the
+// second block does not fit and the kernel silently runs at half occupancy (17.8 -> 28.1 ms).
 template <bool DROPOUT, int PPL, bool STAMP, bool ROOT>
-__global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
+__global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode4_kernel(EncodeParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
     constexpr uint32_t SPAN = 16u * PPL;  // positions per row and iteration
@@ -406,6 +416,8 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
     double acc = ninf;            // best[e] of the end position this lane accumulates; -inf = none yet
     uint32_t bpv = kNoStep;       // step (source position mod 16) that pushed the current best
     uint32_t wn[4 * PPL + 1];  // prefetched text window of the next block
+    uint32_t pk = 0, pk_j = 0;  // back-pointer bytes of this lane's current group of 64 positions, and its last index
+    bool pk_dirty = false;
 #pragma unroll
     for (int q = 0; q <= 4 * PPL; ++q) wn[q] = 0;
     uint64_t seg[6] = {0, 0, 0, 0, 0, 0};
@@ -430,6 +442,7 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
             p0 = 0;
             acc = (l == 0u) ? 0.0 : ninf;  // position 0: score 0, reachable
             bpv = kNoStep;
+            pk_dirty = false;
         }
         const bool fresh_row = need_new;
         need_new = false;
@@ -572,14 +585,27 @@ __global__ __launch_bounds__(1024) void encode4_kernel(EncodeParams P) {
         __builtin_amdgcn_wave_barrier();
         TGX_STAMP(3)  // relax
 
-        // ---- back-pointers of the SPAN positions (streamed past the caches), next block
+        // ---- back-pointers of the SPAN positions (streamed past the caches), next block.  Index j =
+        // end position - 1; a lane's bytes of one 64-position group are packed into a dword (bp8_perm)
+        uint8_t* const bpw = P.bp8 + bp8_base(beg, s);
 #pragma unroll
         for (int g = 0; g < PPL; ++g)
             if (live && pg[g] >= 1u && pg[g] <= n) {
                 // winner pushed at step U = fin into lane l: token length ((l - U - 1) & 15) + 1
-                const uint8_t b = reached[g] ? (uint8_t)((l - fin[g] - 1u) & 15u) : (uint8_t)0xFF;
-                __builtin_nontemporal_store(b, P.bp8 + beg + pg[g] - 1);
+                const uint32_t b = reached[g] ? ((l - fin[g] - 1u) & 15u) : 0xFFu;
+                const uint32_t j = pg[g] - 1u, kq = (j >> 4) & 3u;
+                pk = (kq == 0u) ? b : (pk | (b << (8u * kq)));
+                pk_j = j;
+                pk_dirty = true;
+                if (kq == 3u) {
+                    __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(j) & ~3u)));
+                    pk_dirty = false;
+                }
             }
+        if (live && n - p0 < SPAN && pk_dirty) {  // the sample ends inside a group: flush the partial dword
+            __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(pk_j) & ~3u)));
+            pk_dirty = false;
+        }
         if (live) {
             const uint32_t left = n - p0;
             if (left < SPAN) {  // position n lies in this iteration: the sample is done
@@ -640,7 +666,7 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
         const uint64_t beg = first_u64(P.offs[s]);
         const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
         const uint32_t reach_n = (n == 0) ? 1u : (uint32_t)__builtin_amdgcn_readfirstlane((int)P.status[s]);
-        const uint8_t* __restrict__ bp = P.bp8 + beg;
+        const uint8_t* __restrict__ bp = P.bp8 + bp8_base(beg, s);  // permuted inside groups of 64: bp8_perm
         const uint8_t* __restrict__ text = P.text + beg;
         uint32_t total = 0;
         uint64_t cursor = beg + n;  // one past this sample's slice of tmp
@@ -654,7 +680,7 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
             const uint32_t wq0 = (uint32_t)q & ~63u;
             const uint32_t a0 = wq0 >= 16u ? wq0 - 16u : 0u;
             const uint32_t* __restrict__ gw = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + a0) & ~uintptr_t(3));
-            h_cur = (wq0 + lane < n) ? (uint32_t)bp[wq0 + lane] : 0u;
+            h_cur = (wq0 + lane < n) ? (uint32_t)bp[bp8_perm(wq0 + lane)] : 0u;
             t_cur = (lane <= 20u) ? gw[lane] : 0u;
         }
         TGX_STAMP(0)  // sample setup
@@ -686,7 +712,7 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
                 const uint32_t wn = wq - 64u;
                 const uint32_t an = wn >= 16u ? wn - 16u : 0u;
                 const uint32_t* __restrict__ gwn = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + an) & ~uintptr_t(3));
-                h_next = (uint32_t)bp[wn + lane];
+                h_next = (uint32_t)bp[bp8_perm(wn + lane)];
                 t_next = (lane <= 20u) ? gwn[lane] : 0u;
             }
             if ((ends >> lane) & 1ULL) {

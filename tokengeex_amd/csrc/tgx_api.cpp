@@ -208,7 +208,8 @@ void time_end(tgx_model* m) {
 tgx_status ensure_scratch(tgx_corpus* c) {
     if (c->d_bp) return TGX_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(pool_alloc(c->device, (size_t)c->n_bytes * 4 + 256, (void**)&c->d_bp));
+    // u32[N] for the one-sample-per-wave kernel; the rows4 kernels use it as bytes, N + 128 per sample
+    HIP_TRY(pool_alloc(c->device, std::max((size_t)c->n_bytes * 4 + 256, (size_t)c->n_bytes + 128 * (size_t)c->n_samples + 512), (void**)&c->d_bp));
     HIP_TRY(pool_alloc(c->device, (size_t)c->n_bytes * 4 + 256, (void**)&c->d_tmp));
     HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_counts));
     HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_status));
@@ -657,7 +658,7 @@ void tgx_corpus_free(tgx_corpus* c) {
     pool_free(c->device, c->d_text_alloc, (size_t)c->n_bytes + 512);
     pool_free(c->device, c->d_offs, (size_t)(c->n_samples + 1) * 8);
     pool_free(c->device, c->d_order, (size_t)c->n_samples * 4 + 4);
-    pool_free(c->device, c->d_bp, (size_t)c->n_bytes * 4 + 256);
+    pool_free(c->device, c->d_bp, std::max((size_t)c->n_bytes * 4 + 256, (size_t)c->n_bytes + 128 * (size_t)c->n_samples + 512));
     pool_free(c->device, c->d_tmp, (size_t)c->n_bytes * 4 + 256);
     pool_free(c->device, c->d_counts, (size_t)c->n_samples * 4 + 256);
     pool_free(c->device, c->d_status, (size_t)c->n_samples * 4 + 256);
