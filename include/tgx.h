@@ -187,6 +187,9 @@ tgx_status tgx_prune_select(const uint64_t *freq, const uint8_t *keep, const uin
 int tgx_last_kernel_times(const tgx_model *m, const char **names, float *ms, int cap);
 /* Algorithmic bytes of the last pass, SURVEY.md §8(d): encode N + 4T + 16(S+1). */
 uint64_t tgx_last_algorithmic_bytes(const tgx_model *m);
+/* waves per CU the last four-samples-per-wave encode launch really had resident (occupancy query for
+ * its kernel variant, block size and LDS): a self-check that the launch geometry fits the device. */
+uint32_t tgx_last_encode_waves_per_cu(const tgx_model *m);
 
 /* ---- dropout ---------------------------------------------------------------
  * The reference draws rand::random::<f64>() from an unseeded thread RNG

@@ -210,3 +210,16 @@ def test_non_finite_scores_use_the_exact_generic_path():
         texts = [b"abcab", b"bbbb", b"abab" * 20, b"cab", b"b"]
         assert _enc(nat, texts) == ora.encode_batch(texts), scores
         assert "encode4_kernel" not in nat.last_kernel_times()
+
+
+def test_launch_geometry_fits_the_device(monkeypatch):
+    """The four-samples-per-wave kernel must really have its planned waves resident: two blocks of nine or
+    ten waves put six waves on some SIMD, which needs the kernel to stay within 80 VGPRs (a build that
+    drifted to 82 ran at half occupancy, 28 ms instead of 18 ms per GiB, without failing any parity test)."""
+    flat, offs, toks, scores = corpus_and_vocab(8 << 20, "mixed", 4000, 16, max_len=2048)
+    nat = tgx.NativeModel(toks, scores)
+    monkeypatch.setenv("TGX_PPL", "1")       # one position per lane: the bench's variant, whatever the corpus shape
+    res = nat.encode_batch_flat(flat, offs)
+    res.free()
+    assert "encode4_kernel" in nat.last_kernel_times()
+    assert nat.last_encode_waves_per_cu() >= 18

@@ -65,6 +65,7 @@ SYMBOLS = {
     "tgx_prune_select": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u64, _u32, _vp, C.POINTER(C.c_uint32)]),
     "tgx_last_kernel_times": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i]),
     "tgx_last_algorithmic_bytes": (_u64, [_vp]),
+    "tgx_last_encode_waves_per_cu": (_u32, [_vp]),
 }
 
 
@@ -287,6 +288,9 @@ class NativeModel:
 
     def last_algorithmic_bytes(self) -> int:
         return lib.tgx_last_algorithmic_bytes(self._h)
+
+    def last_encode_waves_per_cu(self) -> int:
+        return lib.tgx_last_encode_waves_per_cu(self._h)
 
 
 class FlatTrie:

@@ -874,6 +874,15 @@ uint32_t encode4_lds_bytes(int waves, int ppl, bool root) {
     return (root ? 4096u : 0u) + (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes;
 }
 // root = true (first trie level in LDS) exists for ppl == 1 only
+// Blocks of `waves` waves of this variant that one CU really holds (registers, LDS, wave slots): what the
+// host checks its geometry against, so that a register-count surprise cannot silently halve the occupancy.
+hipError_t encode4_blocks_per_cu(bool dropout, int ppl, int waves, bool root, int* out) {
+    root = root && ppl == 1;
+    encode4_fn fn = pick_encode4(dropout, ppl, false, root);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, 64 * waves, encode4_lds_bytes(waves, ppl, root));
+}
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream) {
     const bool stamp = p.stamps != nullptr;
     root = root && !stamp && ppl == 1;

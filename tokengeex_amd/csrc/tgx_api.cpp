@@ -127,6 +127,7 @@ struct tgx_model {
     void* d_trie_rev = nullptr;
     void* d_trie_w = nullptr;       // forward / reversed tables with w = exp(score) in place of the score
     void* d_trie_rev_w = nullptr;   //   (linear-domain E-step, estep4l.hip)
+    int last_encode_waves_per_cu = 0;  // resident waves per CU of the last rows4 encode launch (self-check)
     bool estep_linear_ok = false;   // tables for the linear-domain E-step kernels exist
     tgx::TokHashTable tokhash;      // token bytes -> id (rows4 trace); ok == false: not usable
     void* d_tokhash = nullptr;
@@ -302,6 +303,20 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         bool root = ppl == 1;  // first trie level in LDS (4 KiB per block)
         if (const char* e = getenv("TGX_ROOT")) root = root && atoi(e) != 0;
         while (waves > 1 && tgx::encode4_lds_bytes(waves, ppl, root) > (160u * 1024u) / (uint32_t)bpc) waves--;
+        {
+            // the geometry must really fit: `bpc` blocks of `waves` waves per CU (see encode4_kernel's note
+            // on registers); otherwise fall back to five blocks of four waves, one wave per SIMD and block
+            int fit = 0;
+            HIP_TRY(tgx::encode4_blocks_per_cu(dropout > 0.0, ppl, waves, root, &fit));
+            m->last_encode_waves_per_cu = std::min(fit, bpc) * waves;
+            if (fit < bpc && ppl == 1) {
+                waves = 4;
+                bpc = 5;
+                root = false;
+                HIP_TRY(tgx::encode4_blocks_per_cu(dropout > 0.0, ppl, waves, root, &fit));
+                m->last_encode_waves_per_cu = std::min(fit, bpc) * waves;
+            }
+        }
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
             1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
@@ -1237,6 +1252,7 @@ int tgx_last_kernel_times(const tgx_model* m, const char** names, float* ms, int
     return n;
 }
 
+uint32_t tgx_last_encode_waves_per_cu(const tgx_model* m) { return m ? (uint32_t)m->last_encode_waves_per_cu : 0u; }
 uint64_t tgx_last_algorithmic_bytes(const tgx_model* m) { return m ? m->last_alg_bytes : 0; }
 
 }  // extern "C"
