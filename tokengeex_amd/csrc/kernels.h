@@ -121,7 +121,7 @@ uint32_t encode_waves_per_block(uint32_t lm);
 hipError_t encode_max_blocks_per_cu(uint32_t lm, int* out);
 hipError_t launch_encode(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 uint32_t encode4_group_bytes();
-hipError_t encode4_blocks_per_cu(bool dropout, int ppl, int waves, bool root, int* out);
+hipError_t encode4_waves_per_simd(bool dropout, int ppl, bool root, int* out);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream);
 uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);

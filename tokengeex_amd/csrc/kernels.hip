@@ -874,14 +874,18 @@ uint32_t encode4_lds_bytes(int waves, int ppl, bool root) {
     return (root ? 4096u : 0u) + (uint32_t)waves * (uint32_t)ppl * kRows4GroupBytes;
 }
 // root = true (first trie level in LDS) exists for ppl == 1 only
-// Blocks of `waves` waves of this variant that one CU really holds (registers, LDS, wave slots): what the
-// host checks its geometry against, so that a register-count surprise cannot silently halve the occupancy.
-hipError_t encode4_blocks_per_cu(bool dropout, int ppl, int waves, bool root, int* out) {
+// Waves of this variant that one SIMD can hold by its vector registers (512 per lane and SIMD, allocated
+// in units of 8, at most 8 waves): what the host checks its geometry against, so that a register-count
+// surprise cannot silently halve the occupancy.  (hipOccupancyMaxActiveBlocksPerMultiprocessor is of no
+// use here: it does not know the CU's 160 KiB of LDS.)
+hipError_t encode4_waves_per_simd(bool dropout, int ppl, bool root, int* out) {
     root = root && ppl == 1;
-    encode4_fn fn = pick_encode4(dropout, ppl, false, root);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncAttributes attr;
+    hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(pick_encode4(dropout, ppl, false, root)));
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, fn, 64 * waves, encode4_lds_bytes(waves, ppl, root));
+    const int regs = (attr.numRegs + 7) & ~7;
+    *out = regs > 0 ? (512 / regs > 8 ? 8 : 512 / regs) : 8;
+    return hipSuccess;
 }
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream) {
     const bool stamp = p.stamps != nullptr;

@@ -285,13 +285,13 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                     ppl = 1 << i;
                 }
             }
-            if (ppl == 2) { waves = 5; bpc = 2; }
-            if (ppl == 4) { waves = 5; bpc = 1; }
         }
         if (const char* e = getenv("TGX_PPL")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) ppl = v;
         }
+        if (ppl == 2) { waves = 5; bpc = 2; }
+        if (ppl == 4) { waves = 5; bpc = 1; }
         if (const char* e = getenv("TGX_WAVES")) {
             const int v = atoi(e);
             if (v >= 1 && v <= 16) waves = v;
@@ -304,18 +304,20 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         if (const char* e = getenv("TGX_ROOT")) root = root && atoi(e) != 0;
         while (waves > 1 && tgx::encode4_lds_bytes(waves, ppl, root) > (160u * 1024u) / (uint32_t)bpc) waves--;
         {
-            // the geometry must really fit: `bpc` blocks of `waves` waves per CU (see encode4_kernel's note
-            // on registers); otherwise fall back to five blocks of four waves, one wave per SIMD and block
-            int fit = 0;
-            HIP_TRY(tgx::encode4_blocks_per_cu(dropout > 0.0, ppl, waves, root, &fit));
-            m->last_encode_waves_per_cu = std::min(fit, bpc) * waves;
-            if (fit < bpc && ppl == 1) {
+            // The geometry must really fit: a block's waves are dealt round-robin to the four SIMDs, so
+            // `bpc` blocks put bpc * ceil(waves / 4) waves on some SIMD, which its registers must allow
+            // (see encode4_kernel's note); otherwise five blocks of four waves: one wave per SIMD and block.
+            int per_simd = 0;
+            HIP_TRY(tgx::encode4_waves_per_simd(dropout > 0.0, ppl, root, &per_simd));
+            if (bpc * ((waves + 3) / 4) > per_simd && ppl == 1) {
                 waves = 4;
-                bpc = 5;
+                bpc = std::min(5, per_simd);
                 root = false;
-                HIP_TRY(tgx::encode4_blocks_per_cu(dropout > 0.0, ppl, waves, root, &fit));
-                m->last_encode_waves_per_cu = std::min(fit, bpc) * waves;
+                HIP_TRY(tgx::encode4_waves_per_simd(dropout > 0.0, ppl, root, &per_simd));
             }
+            m->last_encode_waves_per_cu = std::min(bpc * ((waves + 3) / 4), per_simd) * 4 >= bpc * waves
+                                              ? bpc * waves
+                                              : per_simd / ((waves + 3) / 4) * waves;
         }
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
