@@ -72,3 +72,35 @@ def test_shard_bounds_edge_cases():
     assert b[0][0] == 0 and b[-1][1] == 4 and all(b[i][1] == b[i + 1][0] for i in range(2))
     b = tdist.shard_bounds(np.array([0, 5], dtype=np.uint64), 4)  # more ranks than samples
     assert sum(hi - lo for lo, hi in b) == 1
+
+
+def _pairs_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flat, offs = synth.make_corpus(256 << 10, "mixed")
+        toks, scores = synth.build_vocab(flat, 800, 12)
+        lo, hi = tdist.shard_bounds(offs, world)[rank]
+        sflat, soffs = tdist.take_shard(flat, offs, lo, hi)
+        keys, counts = orc.OracleModel(toks, scores).count_pairs_flat(sflat, soffs)  # stands in for the GPU scan
+        k, c = tdist.allreduce_pairs(keys, counts, dist)
+        n = tdist.allreduce_scalar(hi - lo, dist)
+        np.savez(os.path.join(out_dir, f"p{rank}.npz"), k=k, c=c, n=n)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pair_table_merge(tmp_path):
+    """dist.allreduce_pairs: the merged (key, count) table is the table of the whole corpus, on every rank
+    (pairs never span samples, src/merge.rs:60-63, so sharding by samples loses none)."""
+    world, port = 2, _free_port()
+    mp.spawn(_pairs_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / "p0.npz"), np.load(tmp_path / "p1.npz")
+    flat, offs = synth.make_corpus(256 << 10, "mixed")
+    toks, scores = synth.build_vocab(flat, 800, 12)
+    wk, wc = orc.OracleModel(toks, scores).count_pairs_flat(flat, offs)
+    for p in (p0, p1):
+        np.testing.assert_array_equal(p["k"], wk)
+        np.testing.assert_array_equal(p["c"], wc)
+        assert int(p["n"]) == offs.size - 1

@@ -60,3 +60,35 @@ def aggregate_timing(elapsed: float, n_bytes: int, n_tokens: int, dist=None, dev
     s = torch.tensor([float(n_bytes), float(n_tokens)], dtype=torch.float64, device=device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t.item()), float(s[0].item()), float(s[1].item())
+
+
+def allreduce_scalar(x: int, dist=None, device: str = "cpu") -> int:
+    """Sum of one integer per rank."""
+    return int(allreduce_vector(np.array([x], np.uint64), dist, device)[0])
+
+
+def allreduce_pairs(keys: np.ndarray, counts: np.ndarray, dist=None, device: str = "cpu"):
+    """Merge of the per-rank (key, count) tables of the pair scan (reference src/merge.rs:66-71 merges its
+    per-chunk maps under a lock): every rank gathers all tables (padded to the longest) and adds the counts
+    of equal keys -> the same sorted table on every rank.  A few MB per rank, once per merge round."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return keys.copy(), counts.copy()
+    import torch
+    world = dist.get_world_size()
+    n = torch.tensor([keys.size], dtype=torch.int64, device=device)
+    sizes = [torch.empty_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    width = max(max(sizes), 1)
+    buf = np.zeros((2, width), np.int64)
+    buf[0, :keys.size] = keys.view(np.int64)
+    buf[1, :counts.size] = counts.view(np.int64)
+    t = torch.from_numpy(buf).to(device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    allk = np.concatenate([parts[r][0, :sizes[r]].cpu().numpy().view(np.uint64) for r in range(world)])
+    allc = np.concatenate([parts[r][1, :sizes[r]].cpu().numpy().view(np.uint64) for r in range(world)])
+    uk, inv = np.unique(allk, return_inverse=True)
+    uc = np.zeros(uk.size, np.uint64)
+    np.add.at(uc, inv, allc)
+    return uk, uc

@@ -14,6 +14,7 @@ import re
 import numpy as np
 
 from . import _lib
+from . import dist as tdist
 
 _POSIX_ASCII = {  # Rust regex: POSIX classes are ASCII only
     "alnum": "0-9A-Za-z", "alpha": "A-Za-z", "ascii": "\\x00-\\x7F", "blank": " \\t", "cntrl": "\\x00-\\x1F\\x7F",
@@ -75,12 +76,15 @@ class ModelVocabularyMerger:
     """ModelVocabularyMerger::new(allow, num_merges, step, scale_factor, max_token_length) — src/merge.rs:16-31."""
 
     def __init__(self, allow, num_merges: int, step: int, scale_factor: float, max_token_length: int,
-                 device: int = 0, log=None):
+                 device: int = 0, log=None, dist=None, reduce_device: str = "cpu"):
         self.allow = compile_rust_regex(allow) if isinstance(allow, str) else allow
         self.num_merges, self.step = int(num_merges), int(step)
         self.scale_factor, self.max_token_length = float(scale_factor), int(max_token_length)
         self.device = device
         self.log = log or (lambda *_: None)
+        # multi-GPU: one process per GPU with its own shard; the per-rank pair tables are merged on every
+        # rank (dist.allreduce_pairs), so all ranks pick the same merges (SURVEY.md §8e)
+        self.dist, self.reduce_device = dist, reduce_device
         self.rounds: list[dict] = []
 
     def select(self, vocab, keys: np.ndarray, counts: np.ndarray, budget: int, ignore: set):
@@ -113,7 +117,7 @@ class ModelVocabularyMerger:
             while len(vocab) < start + self.num_merges:
                 model = _lib.NativeModel([t[0] for t in vocab], [t[1] for t in vocab], self.device)
                 t0 = time.perf_counter()
-                keys, counts = model.count_pairs(corpus)
+                keys, counts = tdist.allreduce_pairs(*model.count_pairs(corpus), self.dist, self.reduce_device)
                 t1 = time.perf_counter()
                 model.free()
                 budget = min(self.step, self.num_merges - (len(vocab) - start))

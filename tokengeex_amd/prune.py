@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 from . import _lib
+from . import dist as tdist
 
 Vocab = list  # list[tuple[bytes, float, bool]]  (value, score, keep) — ScoredToken, src/lib.rs:77-84
 
@@ -22,7 +23,7 @@ class ModelVocabularyPruner:
     """ModelVocabularyPruner::new(vocab_size, shrink_factor, em_subiters, dropout) — src/prune.rs:13-21."""
 
     def __init__(self, vocab_size: int, shrink_factor: float, em_subiters: int, dropout: float,
-                 device: int = 0, seed: int = 0, log=None):
+                 device: int = 0, seed: int = 0, log=None, dist=None, reduce_device: str = "cpu"):
         self.vocab_size = int(vocab_size)
         self.shrink_factor = float(shrink_factor)
         self.em_subiters = int(em_subiters)
@@ -30,6 +31,10 @@ class ModelVocabularyPruner:
         self.device = device
         self.seed = seed
         self.log = log or (lambda *_: None)
+        # multi-GPU: one process per GPU, each with its own shard of the samples; `dist` is an initialised
+        # torch.distributed module.  The only exchange is one vector per pass, summed in rank order, so every
+        # rank derives the same vocabulary (no data-path collective).
+        self.dist, self.reduce_device = dist, reduce_device
         self.timings: list[dict] = []
 
     # -- one pass each ------------------------------------------------------------------
@@ -40,7 +45,7 @@ class ModelVocabularyPruner:
         """src/prune.rs:64-120 (81 920-byte snippets; z must be normal)."""
         self.seed += 1
         expected, _ = model.estep(corpus, _lib.ESTEP_SNIPPET_LEN, self.dropout, self.seed)
-        return expected
+        return tdist.allreduce_vector(expected, self.dist, self.reduce_device)
 
     @staticmethod
     def run_m_step(vocab: Vocab, expected: np.ndarray) -> Vocab:
@@ -58,9 +63,9 @@ class ModelVocabularyPruner:
         keep = np.array([1 if t[2] else 0 for t in vocab], np.uint8)
         trie = _lib.FlatTrie(tokens, scores)
         always_keep, alt_offs, alt_ids = trie.prune_alternatives(tokens, scores)
-        freq = model.count_tokens(corpus)
-        out = _lib.prune_select(freq, keep, always_keep, alt_offs, alt_ids, scores, corpus.num_samples,
-                                pruned_size)
+        freq = tdist.allreduce_vector(model.count_tokens(corpus), self.dist, self.reduce_device)
+        n_samples = tdist.allreduce_scalar(corpus.num_samples, self.dist, self.reduce_device)
+        out = _lib.prune_select(freq, keep, always_keep, alt_offs, alt_ids, scores, n_samples, pruned_size)
         return [vocab[int(i)] for i in out]
 
     # -- the loop -----------------------------------------------------------------------
