@@ -79,15 +79,20 @@ __device__ __forceinline__ void e4l_bwd_step(double sv, uint32_t hv, double c_cu
     acc = sel_f64(MU, cand, acc + cand);
 }
 
-template <bool DROPOUT>
-__global__ __launch_bounds__(256) void estep4l_fwd_kernel(Estep4Params P) {
+// PPL = positions per lane and trip (1, 2, 4): a row advances 16 * PPL positions per trip of the dependent
+// gather chain.  The relaxation is cheap here (one multiply-add per step), so more positions per lane shorten
+// the serial chain of a long snippet almost proportionally, at the price of LDS (8 KiB * PPL per wave
+// forward, 12 KiB * PPL backward) and with it waves per CU; the host picks PPL from the shape of the pass.
+template <bool DROPOUT, int PPL>
+__global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
+    constexpr uint32_t SPAN = 16u * PPL;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie_fwd);  // records carry w = exp(score)
-    double* sc = reinterpret_cast<double*>(smem + (size_t)wave * (kE4LEntries * 8u));
+    double* sc = reinterpret_cast<double*>(smem + (size_t)wave * (PPL * kE4LEntries * 8u));
 
     uint32_t s = 0, n = 0, p0 = 0, smp = 0;
     uint64_t beg = 0, sbase = 0, ebase = 0;
@@ -118,52 +123,78 @@ __global__ __launch_bounds__(256) void estep4l_fwd_kernel(Estep4Params P) {
         if (__builtin_amdgcn_ballot_w64(live) == 0) break;
 
         // ---- match (forward trie), as in encode4_kernel; "no token" = weight 0
-        const uint32_t p = p0 + l;
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p : 0));
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p0 + l : 0));
         const uint32_t sh = (uint32_t)(addr & 3u);
         const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
-        uint32_t w[5];
+        uint32_t w[4 * PPL + 1];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) w[q] = wp[q];
-        uint32_t bytes[4];
+        for (int q = 0; q <= 4 * PPL; ++q) w[q] = wp[q];
+        uint32_t bytes[PPL][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bytes[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh);
-        {
-            double2* grp = reinterpret_cast<double2*>(sc);
+        for (int g = 0; g < PPL; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bytes[g][q] = __builtin_amdgcn_alignbyte(w[4 * g + q + 1], w[4 * g + q], sh);
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            double2* grp = reinterpret_cast<double2*>(sc + g * kE4LEntries);
 #pragma unroll
             for (int q = 0; q < 8; ++q) grp[q * 64 + lane] = make_double2(0.0, 0.0);
         }
-        const uint32_t rem = (live && p < n) ? (n - p) : 0u;
-        const uint32_t maxd = rem < LM ? rem : LM;
-        uint32_t cur = 0, base = P.root_fwd;
-        bool alive = maxd > 0;
-        double* scw = sc + lane * LM;
+        uint32_t pg[PPL], maxd[PPL], cur[PPL], base[PPL];
+        bool alive[PPL];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            pg[g] = p0 + 16u * g + l;
+            const uint32_t rem = (live && pg[g] < n) ? (n - pg[g]) : 0u;
+            maxd[g] = rem < LM ? rem : LM;
+            cur[g] = 0;
+            base[g] = P.root_fwd;
+            alive[g] = maxd[g] > 0;
+        }
 #pragma unroll
         for (int d = 0; d < (int)LM; ++d) {
-            alive = alive && ((uint32_t)d < maxd);
-            if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
-            if (alive) {
-                const uint32_t c = (bytes[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
-                const uint32_t t = base ^ c;
-                const uint4 rec = load_rec(trie, t);
-                alive = rec.x == cur;
-                if (alive) {
-                    cur = t;
-                    base = rec.y & 0x7FFFFFFFu;
-                    bool term = (rec.y >> 31) != 0u;
-                    if (DROPOUT) {  // model.rs:48: skipped iff len > 1 && rand < dropout
-                        if (term && d >= 1) term = !(dropout_u01(P.seed, smp, sbase + p, (uint32_t)d + 1u) < P.dropout);
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < PPL; ++g) {
+                alive[g] = alive[g] && ((uint32_t)d < maxd[g]);
+                any = any || alive[g];
+            }
+            if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+            if (any) {
+                uint4 rec[PPL];
+                uint32_t t[PPL];
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) {  // all of this lane's gathers of the step are issued before any is consumed
+                    const uint32_t c = (bytes[g][d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+                    t[g] = alive[g] ? (base[g] ^ c) : 0u;
+                    rec[g] = trie[t[g]];
+                }
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) asm volatile("" : "+v"(rec[g].x), "+v"(rec[g].y), "+v"(rec[g].z), "+v"(rec[g].w));
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) {
+                    alive[g] = alive[g] && rec[g].x == cur[g];
+                    if (alive[g]) {
+                        cur[g] = t[g];
+                        base[g] = rec[g].y & 0x7FFFFFFFu;
+                        bool term = (rec[g].y >> 31) != 0u;
+                        if (DROPOUT) {  // model.rs:48: skipped iff len > 1 && rand < dropout
+                            if (term && d >= 1) term = !(dropout_u01(P.seed, smp, sbase + pg[g], (uint32_t)d + 1u) < P.dropout);
+                        }
+                        if (term) (sc + g * kE4LEntries + lane * LM)[((uint32_t)d + l) & 15u] = __hiloint2double((int)rec[g].w, (int)rec[g].z);
                     }
-                    if (term) scw[((uint32_t)d + l) & 15u] = __hiloint2double((int)rec.w, (int)rec.z);
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- forward recursion, 16 static steps
-        double fin = 0.0;
-        {
-            const double* scr = sc + r * 256u + ((l - 1u) & 15u);
+        // ---- forward recursion: 16 static steps per group of 16 positions, then the row is rescaled (its
+        // largest accumulator goes to [0.5, 1)) — the values of a group are stored under the exponent
+        // that was in effect while they were finalised
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            double fin = 0.0;
+            const double* scr = sc + g * kE4LEntries + r * 256u + ((l - 1u) & 15u);
             double sv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) sv[u] = scr[u * 16];
@@ -183,21 +214,14 @@ __global__ __launch_bounds__(256) void estep4l_fwd_kernel(Estep4Params P) {
             e4l_fwd_step<13>(sv[13], acc, fin);
             e4l_fwd_step<14>(sv[14], acc, fin);
             e4l_fwd_step<15>(sv[15], acc, fin);
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- a[p0 .. p0+15] and the block's exponent -> scratch (snippet s: n + 1 values at soffs[s] + s)
-        if (live && p <= n) {
-            P.alpha[beg + s + p] = fin;
-            // a position nothing was pushed to (lattice.rs:255: it counts as log-probability 0.0 there), an
-            // underflow or an overflow: this pass belongs to the log-domain kernels
-            if (!(fin > 0.0 && fin <= 1.7976931348623157e308)) atomicMax(P.range_flag, 1ULL);
-        }
-        if (live && l == 0u) P.alpha_exp[ebase + (p0 >> 4)] = erow;
-        if (live) {
-            const uint32_t left = n - p0;
-            if (left < 16u) {  // position n lies in this block: z = log alpha_true[n] (lattice.rs:290-291)
-                if (l == left) {
+            // a[pg] and the block's exponent -> scratch (snippet s: n + 1 values at soffs[s] + s)
+            if (live && pg[g] <= n) {
+                P.alpha[beg + s + pg[g]] = fin;
+                // a position nothing was pushed to (lattice.rs:255: it counts as log-probability 0.0 there), an
+                // underflow or an overflow: this pass belongs to the log-domain kernels
+                if (!(fin > 0.0 && fin <= 1.7976931348623157e308)) atomicMax(P.range_flag, 1ULL);
+                if (l == 0u) P.alpha_exp[ebase + (pg[g] >> 4)] = erow;
+                if (pg[g] == n) {  // z = log alpha_true[n] (lattice.rs:290-291)
                     const double z = log(fin) + (double)erow * 0.6931471805599453;
                     P.zarr[s] = z;
                     zsum += z;
@@ -206,35 +230,37 @@ __global__ __launch_bounds__(256) void estep4l_fwd_kernel(Estep4Params P) {
                     if (!(az >= 2.2250738585072014e-308 && az <= 1.7976931348623157e308))
                         atomicMin(P.err_snip, (unsigned long long)s);
                 }
-                need_new = true;
-            } else {
-                p0 += 16u;
             }
-        }
-        // ---- rescale the row: the largest accumulator goes to [0.5, 1)
-        {
             const int e = row_max_exponent(acc);
             if (e > -100000) {
                 acc = ldexp(acc, -e);
                 erow += e;
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            if (n - p0 < SPAN)  // position n lies in this trip: the snippet is done
+                need_new = true;
+            else
+                p0 += SPAN;
+        }
     }
     if (zsum != 0.0) atomicAdd(P.logz_sum, zsum);
 }
 
-template <bool DROPOUT>
+template <bool DROPOUT, int PPL>
 __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
+    constexpr uint32_t SPAN = 16u * PPL;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie_rev);  // records carry w = exp(score)
     double* hot = reinterpret_cast<double*>(smem);  // kHotSlots partial sums, shared by the block
-    unsigned char* wbase = smem + kHotSlots * 8u + (size_t)wave * (kE4LEntries * 12u);
-    double* sc = reinterpret_cast<double*>(wbase);
-    uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + kE4LEntries * 8u);
+    unsigned char* wbase = smem + kHotSlots * 8u + (size_t)wave * (PPL * kE4LEntries * 12u);
+    double* sc = reinterpret_cast<double*>(wbase);                               // PPL groups of scores
+    uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + PPL * kE4LEntries * 8u);  // PPL groups of slots
     // expected counts go to one of n_replicas copies of the slot array (reduced afterwards):
     // a handful of very frequent tokens would otherwise serialise every wave's atomics
     double* __restrict__ expected_slot = P.expected_slot + (size_t)(blockIdx.x % P.n_replicas) * P.n_slots_rev;
@@ -245,8 +271,15 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
     uint32_t s = 0, n = 0, y0 = 0, smp = 0;
     uint64_t beg = 0, sbase = 0, ebase = 0;
     bool live = false, need_new = true;
-    double acc = 0.0, inv_an = 0.0, c_cur = 0.0, c_nxt = 0.0;
-    int eb = 0, ean = 0, e_cur = 0, e_nxt = 0;
+    double acc = 0.0, inv_an = 0.0;
+    double cfw[PPL + 1];  // a[p] / a[n] of this lane's start positions y0 + 16 g + l, g = 0 .. PPL
+    int efw[PPL + 1];     // Ea(p) - Ea(n)
+    int eb = 0, ean = 0;
+#pragma unroll
+    for (int g = 0; g <= PPL; ++g) {
+        cfw[g] = 0.0;
+        efw[g] = 0;
+    }
 
     // (a[p] / a[n], Ea(p) - Ea(n)) of the start position with distance y from the end, (0, 0) past the start
     auto load_fwd = [&](uint32_t y, double& c, int& e) {
@@ -279,67 +312,96 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
             y0 = 0;
             acc = (l == 0u) ? 1.0 : 0.0;  // EOS: beta = 0 in the log domain
             eb = 0;
-            load_fwd(l, c_cur, e_cur);
-            load_fwd(16u + l, c_nxt, e_nxt);
+#pragma unroll
+            for (int g = 0; g <= PPL; ++g) load_fwd(16u * g + l, cfw[g], efw[g]);
         }
         need_new = false;
         if (__builtin_amdgcn_ballot_w64(live) == 0) break;
 
-        // ---- match on the reversed text with the reversed-token trie: lane (r, l) owns end
-        // position q = n - y, y = y0 + l, and reads text[q - 1], text[q - 2], ...
-        const uint32_t y = y0 + l;
-        const uint32_t q = (live && y < n) ? (n - y) : 0u;  // bytes available before q
-        const uint32_t maxd = q < LM ? q : LM;
-        // the 16 bytes text[q - 16 .. q) (the buffer has a 256-byte front pad)
-        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + (uint64_t)(n - (y < n ? y : n)) : 16u)) - 16u;
+        // ---- match on the reversed text with the reversed-token trie: lane (r, l) owns the end positions
+        // q = n - y, y = y0 + 16 g + l, and reads text[q - 1], text[q - 2], ...  The 16-byte windows
+        // text[q - 16 .. q) of a lane's PPL positions are adjacent (16 bytes apart, descending with g), so
+        // one span of 4 PPL + 1 dwords starting at the lowest covers them (the buffer has a 256-byte front
+        // pad; windows of positions before the snippet's start are read but never used)
+        uint32_t yq[PPL], qq[PPL], maxd[PPL], cur[PPL], base[PPL];
+        bool alive[PPL];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            yq[g] = y0 + 16u * g + l;
+            qq[g] = (live && yq[g] < n) ? (n - yq[g]) : 0u;  // bytes available before q
+            maxd[g] = qq[g] < LM ? qq[g] : LM;
+            cur[g] = 0;
+            base[g] = P.root_rev;
+            alive[g] = maxd[g] > 0;
+        }
+        const int64_t low = live ? (int64_t)beg + (int64_t)n - (int64_t)(y0 + 16u * (PPL - 1) + l) - 16 : 0;
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text) + (uintptr_t)(low < -240 ? -240 : low);
         const uint32_t sh = (uint32_t)(addr & 3u);
         const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
-        uint32_t w[5];
+        uint32_t w[4 * PPL + 1];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) w[j] = wp[j];
-        uint32_t bytes[4];
+        for (int j = 0; j <= 4 * PPL; ++j) w[j] = wp[j];
+        uint32_t bytes[PPL][4];  // group g's window sits 16 (PPL - 1 - g) bytes above the lowest
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bytes[j] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
-        {
-            double2* grp = reinterpret_cast<double2*>(sc);
+        for (int g = 0; g < PPL; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bytes[g][j] = __builtin_amdgcn_alignbyte(w[4 * (PPL - 1 - g) + j + 1], w[4 * (PPL - 1 - g) + j], sh);
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            double2* grp = reinterpret_cast<double2*>(sc + g * kE4LEntries);
 #pragma unroll
             for (int j = 0; j < 8; ++j) grp[j * 64 + lane] = make_double2(0.0, 0.0);
         }
-        uint32_t cur = 0, base = P.root_rev;
-        bool alive = maxd > 0;
-        double* scw = sc + lane * LM;
-        uint32_t* hlw = hl + lane * LM;
 #pragma unroll
         for (int d = 0; d < (int)LM; ++d) {
-            alive = alive && ((uint32_t)d < maxd);
-            if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
-            if (alive) {
-                const uint32_t c = (bytes[(15 - d) >> 2] >> (((15 - d) & 3) * 8)) & 0xFFu;  // text[q - 1 - d]
-                const uint32_t t = base ^ c;
-                const uint4 rec = load_rec(trie, t);
-                alive = rec.x == cur;
-                if (alive) {
-                    cur = t;
-                    base = rec.y & 0x7FFFFFFFu;
-                    bool term = (rec.y >> 31) != 0u;
-                    if (DROPOUT) {  // keyed by the token's START byte in the sample, as in the forward sweep
-                        if (term && d >= 1)
-                            term = !(dropout_u01(P.seed, smp, sbase + (uint64_t)(q - (uint32_t)d - 1u), (uint32_t)d + 1u) < P.dropout);
-                    }
-                    if (term) {
-                        const uint32_t col = ((uint32_t)d + l) & 15u;
-                        scw[col] = __hiloint2double((int)rec.w, (int)rec.z);
-                        hlw[col] = t;
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < PPL; ++g) {
+                alive[g] = alive[g] && ((uint32_t)d < maxd[g]);
+                any = any || alive[g];
+            }
+            if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+            if (any) {
+                uint4 rec[PPL];
+                uint32_t t[PPL];
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) {
+                    const uint32_t c = (bytes[g][(15 - d) >> 2] >> (((15 - d) & 3) * 8)) & 0xFFu;  // text[q - 1 - d]
+                    t[g] = alive[g] ? (base[g] ^ c) : 0u;
+                    rec[g] = trie[t[g]];
+                }
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) asm volatile("" : "+v"(rec[g].x), "+v"(rec[g].y), "+v"(rec[g].z), "+v"(rec[g].w));
+#pragma unroll
+                for (int g = 0; g < PPL; ++g) {
+                    alive[g] = alive[g] && rec[g].x == cur[g];
+                    if (alive[g]) {
+                        cur[g] = t[g];
+                        base[g] = rec[g].y & 0x7FFFFFFFu;
+                        bool term = (rec[g].y >> 31) != 0u;
+                        if (DROPOUT) {  // keyed by the token's START byte in the sample, as in the forward sweep
+                            if (term && d >= 1)
+                                term = !(dropout_u01(P.seed, smp, sbase + (uint64_t)(qq[g] - (uint32_t)d - 1u), (uint32_t)d + 1u) < P.dropout);
+                        }
+                        if (term) {
+                            const uint32_t col = ((uint32_t)d + l) & 15u;
+                            (sc + g * kE4LEntries + lane * LM)[col] = __hiloint2double((int)rec[g].w, (int)rec[g].z);
+                            (hl + g * kE4LEntries + lane * LM)[col] = t[g];
+                        }
                     }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- backward recursion + marginals, 16 static steps
-        {
-            const double* scr = sc + r * 256u + ((l - 1u) & 15u);
-            const uint32_t* hlr = hl + r * 256u + ((l - 1u) & 15u);
+        // ---- backward recursion + marginals: 16 static steps per group, then the row is rescaled
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            const double* scr = sc + g * kE4LEntries + r * 256u + ((l - 1u) & 15u);
+            const uint32_t* hlr = hl + g * kE4LEntries + r * 256u + ((l - 1u) & 15u);
+            const double c_cur = cfw[g], c_nxt = cfw[g + 1];
+            const int e_cur = efw[g], e_nxt = efw[g + 1];
             double sv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) sv[u] = scr[u * 16];
@@ -359,25 +421,23 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
             e4l_bwd_step<13>(sv[13], hlr[13 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
             e4l_bwd_step<14>(sv[14], hlr[14 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
             e4l_bwd_step<15>(sv[15], hlr[15 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        if (live) {
-            const uint32_t left = n - y0;
-            if (left < 16u) {  // position 0 lies in this block: the snippet is done
-                need_new = true;
-            } else {
-                y0 += 16u;
-                c_cur = c_nxt;
-                e_cur = e_nxt;
-                load_fwd(y0 + 16u + l, c_nxt, e_nxt);
-            }
-        }
-        {
             const int e = row_max_exponent(acc);
             if (e > -100000) {
                 acc = ldexp(acc, -e);
                 eb += e;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        if (live) {
+            if (n - y0 < SPAN) {  // position 0 lies in this trip: the snippet is done
+                need_new = true;
+            } else {
+                y0 += SPAN;
+                cfw[0] = cfw[PPL];
+                efw[0] = efw[PPL];
+#pragma unroll
+                for (int g = 1; g <= PPL; ++g) load_fwd(y0 + 16u * g + l, cfw[g], efw[g]);
             }
         }
     }
@@ -389,40 +449,47 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
     }
 }
 
-hipError_t estep4l_prepare() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(estep4l_fwd_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(estep4l_fwd_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(estep4l_bwd_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(estep4l_bwd_kernel<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+typedef void (*estep4l_fn)(Estep4Params);
+static estep4l_fn pick_fwd(bool dropout, int ppl) {
+    if (ppl == 4) return dropout ? estep4l_fwd_kernel<true, 4> : estep4l_fwd_kernel<false, 4>;
+    if (ppl == 2) return dropout ? estep4l_fwd_kernel<true, 2> : estep4l_fwd_kernel<false, 2>;
+    return dropout ? estep4l_fwd_kernel<true, 1> : estep4l_fwd_kernel<false, 1>;
+}
+static estep4l_fn pick_bwd(bool dropout, int ppl) {
+    if (ppl == 4) return dropout ? estep4l_bwd_kernel<true, 4> : estep4l_bwd_kernel<false, 4>;
+    if (ppl == 2) return dropout ? estep4l_bwd_kernel<true, 2> : estep4l_bwd_kernel<false, 2>;
+    return dropout ? estep4l_bwd_kernel<true, 1> : estep4l_bwd_kernel<false, 1>;
 }
 
-// forward: 8 KiB of LDS per wave (5 blocks x 4 waves per CU); backward: 12 KiB (3 x 4)
-hipError_t launch_estep4l_fwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream) {
-    const uint64_t want = (p.n_snips + 15) / 16;
-    const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus * 5 ? (want ? want : 1) : (uint64_t)num_cus * 5);
-    if (p.dropout > 0.0)
-        hipLaunchKernelGGL(estep4l_fwd_kernel<true>, dim3(blocks), dim3(256), 4u * kE4LEntries * 8u, stream, p);
-    else
-        hipLaunchKernelGGL(estep4l_fwd_kernel<false>, dim3(blocks), dim3(256), 4u * kE4LEntries * 8u, stream, p);
+hipError_t estep4l_prepare() {
+    for (int d = 0; d < 2; d++)
+        for (int ppl = 1; ppl <= 4; ppl *= 2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_fwd(d == 1, ppl)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_bwd(d == 1, ppl)),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
+// forward: 8 KiB * ppl of LDS per wave: 5 blocks x 4 waves / 2 x 5 / 1 x 5 per CU for ppl = 1 / 2 / 4
+hipError_t launch_estep4l_fwd(const Estep4Params& p, int ppl, uint32_t num_cus, hipStream_t stream) {
+    const uint32_t waves = ppl == 1 ? 4u : 5u, bpc = ppl == 1 ? 5u : (ppl == 2 ? 2u : 1u);
+    const uint64_t want = (p.n_snips + 4 * waves - 1) / (4 * waves);
+    const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus * bpc ? (want ? want : 1) : (uint64_t)num_cus * bpc);
+    hipLaunchKernelGGL(pick_fwd(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * waves), waves * (uint32_t)ppl * kE4LEntries * 8u,
+                       stream, p);
     return hipGetLastError();
 }
-// backward: ONE block of 12 waves per CU: 12 x 12 KiB of match buffers + 16 KiB of hot-slot sums = 160 KiB
-hipError_t launch_estep4l_bwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream) {
-    const uint32_t waves = 12;
+// backward: ONE block per CU: 12 / 6 / 3 waves x 12 KiB * ppl of match buffers + 16 KiB of hot-slot sums = 160 KiB
+hipError_t launch_estep4l_bwd(const Estep4Params& p, int ppl, uint32_t num_cus, hipStream_t stream) {
+    const uint32_t waves = 12u / (uint32_t)ppl;
     const uint64_t want = (p.n_snips + 4 * waves - 1) / (4 * waves);
     const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus ? (want ? want : 1) : (uint64_t)num_cus);
-    const uint32_t lds = kHotSlots * 8u + waves * kE4LEntries * 12u;
-    if (p.dropout > 0.0)
-        hipLaunchKernelGGL(estep4l_bwd_kernel<true>, dim3(blocks), dim3(64u * waves), lds, stream, p);
-    else
-        hipLaunchKernelGGL(estep4l_bwd_kernel<false>, dim3(blocks), dim3(64u * waves), lds, stream, p);
+    const uint32_t lds = kHotSlots * 8u + waves * (uint32_t)ppl * kE4LEntries * 12u;
+    hipLaunchKernelGGL(pick_bwd(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * waves), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -1090,6 +1090,27 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     // The linear-domain kernels are tried first; if some position of some snippet has no incoming token
     // (lattice.rs:255's 0.0 case, e.g. a byte that is no token) or a value left the f64 range, the forward
     // kernel says so and the pass is redone with the log-domain kernels.
+    // Positions per lane of the linear-domain kernels, chosen per kernel like encode4_kernel's: the longest
+    // snippet is a serial chain (forward 14.5 / 11 / 9 ms, backward 29 / 23 / 23.5 ms per 64 KiB at 1 / 2 / 4
+    // positions per lane) while more positions per lane cost waves (forward 52 / 48 / 33 GB/s, backward
+    // 21 / 16 / 11 GB/s): tools/eppl_sweep.py on 1 x MI355X.  TGX_EPPL overrides both.
+    int eppl_fwd = 1, eppl_bwd = 1;
+    {
+        const double longest = K ? (double)(soffs[order[0] + 1] - soffs[order[0]]) / 65536.0 : 0.0;
+        const double f_gbps[3] = {52.0, 48.0, 33.0}, f_chain[3] = {14.5, 11.0, 9.0};
+        const double b_gbps[3] = {21.0, 16.0, 11.0}, b_chain[3] = {29.0, 23.0, 23.5};
+        double bf = 0, bb = 0;
+        for (int i = 0; i < 3; i++) {
+            const double tf = std::max((double)N / (f_gbps[i] * 1e6), longest * f_chain[i]);
+            const double tb = std::max((double)N / (b_gbps[i] * 1e6), longest * b_chain[i]);
+            if (i == 0 || tf < bf * 0.95) { bf = tf; eppl_fwd = 1 << i; }
+            if (i == 0 || tb < bb * 0.95) { bb = tb; eppl_bwd = 1 << i; }
+        }
+        if (const char* e = getenv("TGX_EPPL")) {
+            const int v = atoi(e);
+            if (v == 1 || v == 2 || v == 4) eppl_fwd = eppl_bwd = v;
+        }
+    }
     bool use_linear = linear;
     for (;;) {
         p.trie_fwd = use_linear ? m->d_trie_w : m->d_trie;
@@ -1099,7 +1120,7 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "E-step queue reset failed"));
         time_begin(m, use_linear ? "estep4l_fwd_kernel" : "estep4_fwd_kernel");
-        if ((use_linear ? tgx::launch_estep4l_fwd(p, (uint32_t)m->num_cus, m->stream)
+        if ((use_linear ? tgx::launch_estep4l_fwd(p, eppl_fwd, (uint32_t)m->num_cus, m->stream)
                         : tgx::launch_estep4_fwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "estep4 forward launch failed"));
         time_end(m);
@@ -1114,7 +1135,7 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             }
         }
         time_begin(m, use_linear ? "estep4l_bwd_kernel" : "estep4_bwd_kernel");
-        if ((use_linear ? tgx::launch_estep4l_bwd(p, (uint32_t)m->num_cus, m->stream)
+        if ((use_linear ? tgx::launch_estep4l_bwd(p, eppl_bwd, (uint32_t)m->num_cus, m->stream)
                         : tgx::launch_estep4_bwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "estep4 backward launch failed"));
         time_end(m);
