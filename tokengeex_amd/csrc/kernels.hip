@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
                 h_next = (uint32_t)bp[bp8_perm(wn + lane)];
                 t_next = (lane <= 20u) ? gwn[lane] : 0u;
             }
-            if ((ends >> lane) & 1ULL) {
+            if (((ends >> lane) & 1ULL) && !(P.flags & 16u)) {  // flags 16: timing experiment, no token phase
                 // token = text[e - len .. e), e = idx + 1
                 const uint32_t len = (h & 15u) + 1u;
                 const uint32_t a0 = wq >= 16u ? wq - 16u : 0u;
