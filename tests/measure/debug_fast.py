@@ -1,6 +1,6 @@
 """Locate the first mismatch between the HIP path and the oracle (debug aid)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import tokengeex_amd as tgx
 from oracle import oracle as orc

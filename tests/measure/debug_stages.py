@@ -1,7 +1,7 @@
 """Staged GPU bring-up: each stage appends a line to gpurun_out/debug.log before it
 starts, so a device fault can be attributed to a stage."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.makedirs("gpurun_out", exist_ok=True)
 LOG = open("gpurun_out/debug.log", "a")
 def log(*a):

@@ -1,7 +1,7 @@
 """Timings of the prune / merge corpus passes (E-step, frequency pass, pair scan) next to
 the CPU oracle on a bounded sample — recorded in profiles/, not part of bench.py's line."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import tokengeex_amd as tgx
 from oracle import oracle as orc
