@@ -223,3 +223,18 @@ def test_launch_geometry_fits_the_device(monkeypatch):
     res.free()
     assert "encode4_kernel" in nat.last_kernel_times()
     assert nat.last_encode_waves_per_cu() >= 18
+
+
+@pytest.mark.parametrize("ppl", ["1", "2", "4"])
+def test_every_positions_per_lane_variant(monkeypatch, ppl):
+    """encode4_kernel exists for 1, 2 and 4 positions per lane (the host normally picks by corpus shape): each
+    bit-exact against the oracle, with samples that end on and off block boundaries, with and without dropout."""
+    monkeypatch.setenv("TGX_PPL", ppl)
+    flat, offs, toks, scores = corpus_and_vocab(512 << 10, "mixed", 3000, 16, seed_offset=23, max_len=20000)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    assert_same_encoding(nat, ora, flat, offs)
+    assert "encode4_kernel" in nat.last_kernel_times()
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.2, seed=5)
+    texts = [b"", b"a", b"ab" * 8, b"ab" * 8 + b"c", b"ab" * 16, b"ab" * 32, b"ab" * 32 + b"a", b"hello world " * 30]
+    f2, o2 = tgx.pack(texts)
+    assert_same_encoding(nat, ora, f2, o2)

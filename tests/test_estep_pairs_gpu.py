@@ -205,3 +205,17 @@ def test_estep_error_budget_against_extended_precision():
     assert e_ora < rtol_for(len(text)), e_ora
     assert e_gpu * 50 < e_ora                      # the deviation between the two is the oracle's rounding
     assert abs(zg - zt) <= 1e-13 * abs(zt) and abs(zo - zt) <= 1e-13 * abs(zt)
+
+
+@pytest.mark.parametrize("eppl", ["1", "2", "4"])
+def test_estep_every_positions_per_lane_variant(monkeypatch, eppl):
+    """The linear-domain kernels exist for 1, 2 and 4 positions per lane (the host normally picks by the shape of
+    the pass): each against the oracle, with snippets that end on and off block boundaries and dropout."""
+    monkeypatch.setenv("TGX_EPPL", eppl)
+    flat, offs, toks, scores = corpus_and_vocab(512 << 10, "mixed", 3000, 16, seed_offset=21, max_len=20000)
+    nat, ora = _pair(toks, scores)
+    _check_estep(nat, ora, flat, offs, snippet_len=4096, dropout=0.1, seed=11)
+    assert "estep4l_bwd_kernel" in nat.last_kernel_times()
+    texts = [b"", b"a", b"ab" * 8, b"ab" * 8 + b"c", b"xyz" * 21 + b"x", b"q" * 64, b"q" * 65, b"hello world " * 30]
+    f2, o2 = tgx.pack(texts)
+    _check_estep(nat, ora, f2, o2, snippet_len=48, dropout=0.0, seed=0)
