@@ -102,8 +102,8 @@ void tgx_flat_trie_stats(const tgx_flat_trie *t, uint64_t *n_slots, uint64_t *n_
 /* copies the slot table: check[n_slots], base_flags[n_slots] (bit 31 = terminal), tokid[n_slots] */
 void tgx_flat_trie_copy(const tgx_flat_trie *t, uint32_t *check, uint32_t *base_flags, uint32_t *tokid);
 /* Builds the token-bytes -> id table the trace kernel probes and looks every token up again through it
- * (host only).  TGX_OK and *mismatches == 0 when every token of <= 16 bytes maps back to the id the trie
- * gives it; TGX_ERR_UNSUPPORTED when the table cannot be built (a token longer than 16 bytes, or no
+ * (host only).  TGX_OK and *mismatches == 0 when every token of <= 32 bytes maps back to the id the trie
+ * gives it; TGX_ERR_UNSUPPORTED when the table cannot be built (a token longer than 32 bytes, or no
  * collision-free seed) — the model then keeps the one-sample-per-wave kernel. */
 tgx_status tgx_tok_hash_selftest(const uint8_t *bytes, const uint64_t *offs, uint32_t vocab_size,
                                  uint32_t *seed, uint64_t *mismatches);

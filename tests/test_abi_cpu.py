@@ -161,5 +161,9 @@ def test_tok_hash_table_is_exact_on_vocabularies():
         o = z["offs"].astype(np.int64); fb = z["flat"].tobytes()
         big = [fb[o[i]:o[i + 1]] for i in range(o.size - 1)]
         assert _lib.tok_hash_selftest(big)[1] == 0
+    # tokens of 17..32 bytes (vocabularies after `merge`): hashed over eight dwords
+    long_toks = adv + [b"abcdefghijklmnopq", b"abcdefghijklmnopqr", b"abcdefghijklmnop" * 2, b"abcdefghijklmnop" + b"abcdefghijklmnoq",
+                       b"\x00" * 17, b"\x00" * 32]
+    assert _lib.tok_hash_selftest(long_toks)[1] == 0
     with pytest.raises(_lib.TokenGeeXError):
-        _lib.tok_hash_selftest([b"x" * 17])
+        _lib.tok_hash_selftest([b"x" * 33])

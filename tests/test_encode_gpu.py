@@ -238,3 +238,21 @@ def test_every_positions_per_lane_variant(monkeypatch, ppl):
     texts = [b"", b"a", b"ab" * 8, b"ab" * 8 + b"c", b"ab" * 16, b"ab" * 32, b"ab" * 32 + b"a", b"hello world " * 30]
     f2, o2 = tgx.pack(texts)
     assert_same_encoding(nat, ora, f2, o2)
+
+
+@pytest.mark.parametrize("max_len", [17, 20, 24, 32])
+def test_two_samples_per_wave_path_for_long_tokens(max_len):
+    """Vocabularies whose longest token has 17..32 bytes (after `merge`) take encode2_kernel + trace32_kernel:
+    bit-exact against the oracle incl. dropout, block-boundary lengths and unreachable ends."""
+    rng = np.random.default_rng(4000 + max_len)
+    flat, offs = synth.make_corpus(384 << 10, "mixed", seed_offset=50 + max_len, max_len=20000)
+    toks, scores = synth.random_vocab(rng, bytes(flat[: 96 << 10]), n_multi=4000, max_len=max_len)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    assert 16 < nat.max_token_len <= max_len
+    assert_same_encoding(nat, ora, flat, offs)
+    assert "encode2_kernel" in nat.last_kernel_times() and "trace32_kernel" in nat.last_kernel_times()
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=9)
+    longest = max(toks, key=len)
+    texts = [b"", b"a", longest, longest * 3, b"ab" * 16, b"ab" * 16 + b"a", b"ab" * 32, b"q" * 31, b"q" * 33, b"hello world " * 40]
+    f2, o2 = tgx.pack(texts)
+    assert_same_encoding(nat, ora, f2, o2)

@@ -1,0 +1,343 @@
+// Viterbi encode for vocabularies whose longest token has 17..32 bytes (vocabularies after `merge`:
+// 20-24 bytes in the reference's recipes): TWO samples per wave on 32-lane rows.
+//
+// Same algorithm and the same bits as encode4_kernel (kernels.hip: four samples per wave on 16-lane DPP
+// rows, which needs max token <= 16): a row advances over blocks of 32 positions, lane l of a row owns
+// position p0 + l in the match phase and accumulates the end position e == l (mod 32) in the relaxation,
+// "no token" is a score of -inf in the LDS match buffer (16 KiB per wave: 64 positions x 32 lengths x 8 B,
+// entry (row, len - 1) at column (len - 1 + row) & 31 so that the reader's column is a per-lane constant),
+// the lane whose position is finalised is restarted by forcing it to take that step's candidate, and only
+// the length of the winning token is remembered (1 byte per position).  What differs is the broadcast of
+// best[p0 + U] inside a row: DPP row_newbcast stops at 16 lanes, so it is two v_readlane pairs (one per
+// row) and a select.  trace32_kernel is trace_kernel for tokens of up to 32 bytes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace tgx {
+
+constexpr uint32_t kNoStep2 = 0xFFu;
+constexpr uint32_t kRows2Bytes = 64u * 32u * 8u;  // 16 KiB per wave
+constexpr uint64_t kHiHalf = 0xFFFFFFFF00000000ULL;  // lanes of row 1
+
+template <int U>
+__device__ __forceinline__ void relax2_step(double sv, double& acc, uint32_t& bpv, uint32_t& fin, uint32_t& fhi) {
+    constexpr uint64_t MU = (1ULL << U) | (1ULL << (32 + U));  // lanes with l == U
+    fin = sel_u32(MU, bpv, fin);                               // winner step of position p0 + U is final now
+    fhi = sel_u32(MU, (uint32_t)((uint64_t)__double_as_longlong(acc) >> 32), fhi);
+    const double b0 = readlane_f64(acc, (uint32_t)U), b1 = readlane_f64(acc, 32u + (uint32_t)U);
+    const double best = sel_f64(kHiHalf, b1, b0);
+    const double cand = best + sv;  // model.rs:98
+    const uint64_t take = __builtin_amdgcn_fcmp(cand, acc, 2 /* OGT: model.rs:101 */) | MU;
+    acc = sel_f64(take, cand, acc);
+    bpv = sel_imm_u32<U>(take, bpv);
+}
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(640) void encode2_kernel(EncodeParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t LM = 32;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = lane & 31u, r = lane >> 5;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
+    double* sc = reinterpret_cast<double*>(smem + (size_t)wave * kRows2Bytes);
+
+    uint32_t s = 0, n = 0, p0 = 0;
+    uint64_t beg = 0;
+    bool live = false, need_new = true;
+    const double ninf = -__builtin_huge_val();
+    double acc = ninf;
+    uint32_t bpv = kNoStep2;
+    uint32_t wn[9];  // prefetched text window of the next block
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wn[q] = 0;
+
+    for (;;) {
+        // ---- rows that finished their sample claim the next one of the longest-first order
+        {
+            const uint64_t want = __builtin_amdgcn_ballot_w64(need_new) & 0x0000000100000001ULL;
+            uint64_t k = ~0ull;
+            if (want != 0) {  // wave-uniform
+                const uint64_t base = wave_fetch_add(P.queue, (uint32_t)__builtin_popcountll(want));
+                if (need_new) k = base + (uint64_t)__builtin_popcountll(want & ((1ull << (r * 32u)) - 1ull));
+            }
+            if (need_new) {
+                live = k < P.n_samples;
+                if (live) {
+                    s = P.order[k];
+                    beg = P.offs[s];
+                    n = (uint32_t)(P.offs[s + 1] - beg);
+                }
+                p0 = 0;
+                acc = (l == 0u) ? 0.0 : ninf;  // position 0: score 0, reachable
+                bpv = kNoStep2;
+            }
+        }
+        const bool fresh_row = need_new;
+        need_new = false;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+
+        // ---- match: 64 trie walks of up to 32 steps; lane (r, l) owns position p0 + l
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p0 + l : 0));
+        const uint32_t sh = (uint32_t)(addr & 3u);
+        const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
+        uint32_t w[9];
+        if (fresh_row) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) w[q] = wp[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) w[q] = wn[q];
+        }
+        uint32_t bytes[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bytes[q] = __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh);
+        {
+            double2* grp = reinterpret_cast<double2*>(sc);  // the wave sweeps its 16 KiB linearly
+#pragma unroll
+            for (int q = 0; q < 16; ++q) grp[q * 64 + lane] = make_double2(ninf, ninf);
+        }
+        const uint32_t pg = p0 + l;
+        const uint32_t rem = (live && pg < n) ? (n - pg) : 0u;
+        const uint32_t maxd = rem < LM ? rem : LM;
+        uint32_t cur = 0, base = P.root_base;
+        bool alive = maxd > 0;
+        double* scw = sc + lane * LM;
+#pragma unroll
+        for (int d = 0; d < (int)LM; ++d) {
+            alive = alive && ((uint32_t)d < maxd);
+            if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+            if (alive) {
+                const uint32_t c = (bytes[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+                const uint32_t t = base ^ c;
+                const uint4 rec = load_rec(trie, t);
+                alive = rec.x == cur;
+                if (alive) {
+                    cur = t;
+                    base = rec.y & 0x7FFFFFFFu;
+                    bool term = (rec.y >> 31) != 0u;
+                    if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
+                        if (term && d >= 1) term = P.dropout < dropout_u01(P.seed, s, pg, (uint32_t)d + 1u);
+                    }
+                    if (term) scw[((uint32_t)d + l) & 31u] = __hiloint2double((int)rec.w, (int)rec.z);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // the following block's text window, requested after the walk's last gather: it lands during the relax
+            const uint32_t* __restrict__ np = wp + 8;  // + 32 bytes, same alignment
+#pragma unroll
+            for (int q = 0; q < 9; ++q) wn[q] = np[q];
+        }
+
+        // ---- relax: 32 static steps, two positions (one per row) per step; the LDS reads of a half are
+        // issued before its dependent chain starts
+        uint32_t fin = kNoStep2, fhi = 0xFFF00000u;
+        {
+            const double* scr = sc + r * 1024u + ((l - 1u) & 31u);  // row (r*32 + U), column (l - 1) & 31
+            double sv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sv[u] = scr[u * 32];
+            relax2_step<0>(sv[0], acc, bpv, fin, fhi);
+            relax2_step<1>(sv[1], acc, bpv, fin, fhi);
+            relax2_step<2>(sv[2], acc, bpv, fin, fhi);
+            relax2_step<3>(sv[3], acc, bpv, fin, fhi);
+            relax2_step<4>(sv[4], acc, bpv, fin, fhi);
+            relax2_step<5>(sv[5], acc, bpv, fin, fhi);
+            relax2_step<6>(sv[6], acc, bpv, fin, fhi);
+            relax2_step<7>(sv[7], acc, bpv, fin, fhi);
+            relax2_step<8>(sv[8], acc, bpv, fin, fhi);
+            relax2_step<9>(sv[9], acc, bpv, fin, fhi);
+            relax2_step<10>(sv[10], acc, bpv, fin, fhi);
+            relax2_step<11>(sv[11], acc, bpv, fin, fhi);
+            relax2_step<12>(sv[12], acc, bpv, fin, fhi);
+            relax2_step<13>(sv[13], acc, bpv, fin, fhi);
+            relax2_step<14>(sv[14], acc, bpv, fin, fhi);
+            relax2_step<15>(sv[15], acc, bpv, fin, fhi);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sv[u] = scr[(u + 16) * 32];
+            relax2_step<16>(sv[0], acc, bpv, fin, fhi);
+            relax2_step<17>(sv[1], acc, bpv, fin, fhi);
+            relax2_step<18>(sv[2], acc, bpv, fin, fhi);
+            relax2_step<19>(sv[3], acc, bpv, fin, fhi);
+            relax2_step<20>(sv[4], acc, bpv, fin, fhi);
+            relax2_step<21>(sv[5], acc, bpv, fin, fhi);
+            relax2_step<22>(sv[6], acc, bpv, fin, fhi);
+            relax2_step<23>(sv[7], acc, bpv, fin, fhi);
+            relax2_step<24>(sv[8], acc, bpv, fin, fhi);
+            relax2_step<25>(sv[9], acc, bpv, fin, fhi);
+            relax2_step<26>(sv[10], acc, bpv, fin, fhi);
+            relax2_step<27>(sv[11], acc, bpv, fin, fhi);
+            relax2_step<28>(sv[12], acc, bpv, fin, fhi);
+            relax2_step<29>(sv[13], acc, bpv, fin, fhi);
+            relax2_step<30>(sv[14], acc, bpv, fin, fhi);
+            relax2_step<31>(sv[15], acc, bpv, fin, fhi);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool reached = fhi != 0xFFF00000u;  // high word of -inf
+
+        // ---- back-pointer of this lane's position (plain bytes: index = end position - 1), next block
+        if (live && pg >= 1u && pg <= n) {
+            // winner pushed at step U = fin into lane l: token length ((l - U - 1) & 31) + 1
+            const uint8_t b = reached ? (uint8_t)((l - fin - 1u) & 31u) : (uint8_t)0xFF;
+            __builtin_nontemporal_store(b, P.bp8 + bp8_base(beg, s) + pg - 1);
+        }
+        if (live) {
+            const uint32_t left = n - p0;
+            if (left < 32u) {  // position n lies in this block: the sample is done
+                if (left == l) P.status[s] = (n == 0u || reached) ? 1u : 0u;
+                need_new = true;
+            } else {
+                p0 += 32u;
+            }
+        }
+    }
+}
+
+// same function as tgx::tok_hash64_long (trie_build.h): tok_hash64 continued over four more dwords
+__device__ __forceinline__ uint64_t tok_hash64_long_dev(const uint32_t* w, uint32_t len, uint32_t seed) {
+    uint32_t a = (w[0] ^ (len << 27) ^ seed) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    uint32_t b = a;
+    a = (a + w[1]) * 0xC2B2AE35u;
+    a ^= a >> 13;
+    b = rotl32_dev(b, 11) ^ a;
+    a = (a + w[2]) * 0x27D4EB2Fu;
+    a ^= a >> 16;
+    b = rotl32_dev(b, 11) ^ a;
+    a = (a + w[3]) * 0x165667B1u;
+    a ^= a >> 15;
+    b = rotl32_dev(b, 11) + (w[0] ^ rotl32_dev(w[1], 8) ^ rotl32_dev(w[2], 16) ^ rotl32_dev(w[3], 24));
+    if (len > 16u) {
+        a = (a + w[4]) * 0x85EBCA6Bu;
+        a ^= a >> 15;
+        b = rotl32_dev(b, 11) ^ a;
+        a = (a + w[5]) * 0xC2B2AE35u;
+        a ^= a >> 13;
+        b = rotl32_dev(b, 11) ^ a;
+        a = (a + w[6]) * 0x27D4EB2Fu;
+        a ^= a >> 16;
+        b = rotl32_dev(b, 11) ^ a;
+        a = (a + w[7]) * 0x165667B1u;
+        a ^= a >> 15;
+        b = rotl32_dev(b, 11) + (w[4] ^ rotl32_dev(w[5], 8) ^ rotl32_dev(w[6], 16) ^ rotl32_dev(w[7], 24));
+    }
+    return ((uint64_t)b << 32) | a;
+}
+
+// trace_kernel (kernels.hip) for tokens of up to 32 bytes: one wave per sample, plain 1-byte back-pointers
+// (token length - 1, 0..31), ids recovered from the token's bytes through the hash table.
+__global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint32_t n_waves = gridDim.x * wpb;
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+    const uint4* __restrict__ table = reinterpret_cast<const uint4*>(P.tokhash);
+    __shared__ uint32_t stage_all[4][40];  // per wave: 96 text bytes + alignment slack + 9-dword over-read
+    uint32_t* stage = stage_all[threadIdx.x >> 6];
+    for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
+        const uint64_t beg = first_u64(P.offs[s]);
+        const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
+        const uint32_t reach_n = (n == 0) ? 1u : (uint32_t)__builtin_amdgcn_readfirstlane((int)P.status[s]);
+        const uint8_t* __restrict__ bp = P.bp8 + bp8_base(beg, s);
+        const uint8_t* __restrict__ text = P.text + beg;
+        uint32_t total = 0;
+        uint64_t cursor = beg + n;  // one past this sample's slice of tmp
+        int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // Error::NoPath(n, n) otherwise (model.rs:119)
+        // windows of 64 positions, top-down; a token is at most 32 bytes, so the next window is always the
+        // one below: its back-pointers and text span (text[wq-32 .. wq+64)) are requested one window ahead
+        auto window_loads = [&](uint32_t wq, uint32_t& hraw, uint32_t& traw) {
+            const uint32_t a0 = wq >= 32u ? wq - 32u : 0u;
+            const uint32_t* __restrict__ gw = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + a0) & ~uintptr_t(3));
+            hraw = (wq + lane < n) ? (uint32_t)bp[wq + lane] : 0u;
+            traw = (lane <= 24u) ? gw[lane] : 0u;
+        };
+        uint32_t h_cur = 0, t_cur = 0;
+        if (q >= 0) window_loads((uint32_t)q & ~63u, h_cur, t_cur);
+        while (q >= 0) {
+            const uint32_t wq = (uint32_t)q & ~63u;
+            const uint32_t idx = wq + lane;
+            const uint32_t h = h_cur;
+            if (lane < 40u) stage[lane] = (lane <= 24u) ? t_cur : 0u;
+            uint64_t ends = 0;
+            int32_t qq = (int32_t)((uint32_t)q - wq);
+            while (qq >= 0) {  // model.rs:113-126, 64 positions per load
+                const uint32_t hh = readlane_u32(h, (uint32_t)qq);
+                ends |= 1ULL << qq;
+                qq -= (int32_t)(hh & 31u) + 1;
+            }
+            q = (int64_t)wq + qq;
+            const uint32_t cnt = (uint32_t)__popcll(ends);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t h_next = 0, t_next = 0;
+            if (wq >= 64u) window_loads(wq - 64u, h_next, t_next);
+            if ((ends >> lane) & 1ULL) {
+                // token = text[e - len .. e), e = idx + 1
+                const uint32_t len = (h & 31u) + 1u;
+                const uint32_t a0 = wq >= 32u ? wq - 32u : 0u;
+                const uintptr_t gaddr = reinterpret_cast<uintptr_t>(text + a0);
+                const uint32_t boff = (uint32_t)(gaddr & 3u) + (idx + 1u - len - a0);  // byte offset in stage[]
+                const uint32_t sh = boff & 3u;
+                const uint32_t* wp = stage + (boff >> 2);
+                uint32_t w[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) w[j] = wp[j];
+                uint32_t b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
+                    const uint32_t nb = len > 4u * j ? len - 4u * j : 0u;  // bytes of the token in this dword
+                    b[j] = nb >= 4u ? v : (v & ((1u << (8u * nb)) - 1u));
+                }
+                const uint64_t hk = tok_hash64_long_dev(b, len, P.tokhash_seed);
+                uint32_t slot = (uint32_t)hk & P.tokhash_mask;
+                uint32_t id = 0;
+                bool found = false;
+                for (uint32_t probe = 0; probe <= P.tokhash_mask && !found; ++probe) {
+                    const uint4 e = table[slot];
+                    if (e.w == 0u) break;  // empty slot: the back-pointer does not name a vocabulary token
+                    if (e.x == (uint32_t)hk && e.y == (uint32_t)(hk >> 32)) {
+                        id = e.z;
+                        found = true;
+                    }
+                    slot = (slot + 1u) & P.tokhash_mask;
+                }
+                // cannot happen unless a kernel bug corrupted a back-pointer: report, do not fault
+                if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
+                const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
+                P.tmp[cursor - 1 - above] = id;
+            }
+            cursor -= cnt;
+            total += cnt;
+            h_cur = h_next;
+            t_cur = t_next;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+            P.counts[s] = total;
+            if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);
+        }
+    }
+}
+
+// two blocks of five waves per CU: 10 x 16 KiB of LDS
+hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, hipStream_t stream) {
+    const uint32_t waves = 5, bpc = 2;
+    const uint64_t want = (p.n_samples + 2 * waves - 1) / (2 * waves);
+    const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus * bpc ? (want ? want : 1) : (uint64_t)num_cus * bpc);
+    auto fn = p.dropout > 0.0 ? encode2_kernel<true> : encode2_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * waves), waves * kRows2Bytes, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(trace32_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace tgx

@@ -125,6 +125,8 @@ hipError_t encode4_waves_per_simd(bool dropout, int ppl, bool root, int* out);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream);
 uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
+hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, hipStream_t stream);   // encode2.hip
+hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);
 hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);
 

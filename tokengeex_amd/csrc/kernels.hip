@@ -329,13 +329,6 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
 // later ones only when strictly greater, absent tokens and unreachable sources give
 // cand = -inf and never win.  This needs every vocabulary score to be finite; models
 // with +-inf / NaN scores use the generic kernel instead.
-// rows4 back-pointer bytes live in a per-sample region of the scratch row that starts at bp8_base(beg, s)
-// and are permuted inside every group of 64 positions so that the four bytes one lane produces in four
-// consecutive trips are adjacent: a row of 16 lanes then writes one full 64-byte segment per group instead
-// of four 16-byte pieces (HBM write traffic of encode4_kernel 3.99 -> ~1.1 GB per GiB of text).
-__device__ __forceinline__ uint64_t bp8_base(uint64_t beg, uint32_t s) { return (beg + 128ull * s) & ~3ull; }
-__device__ __forceinline__ uint32_t bp8_perm(uint32_t j) { return (j & ~63u) | ((j & 15u) << 2) | ((j >> 4) & 3u); }
-
 constexpr uint32_t kNoStep = 0xFFu;  // "nothing pushed into this accumulator yet"
 
 // The winner is remembered as the step U that pushed it; with the lane's own index that
@@ -624,24 +617,6 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode4_kernel(Encod
         for (int i = 0; i < 5; ++i) o[i] = seg[i];
         o[5] = iters;
     }
-}
-
-// same function as tgx::tok_hash64 (trie_build.h)
-__device__ __forceinline__ uint32_t rotl32_dev(uint32_t x, int r) { return __builtin_rotateleft32(x, (uint32_t)r); }
-__device__ __forceinline__ uint64_t tok_hash64_dev(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t len, uint32_t seed) {
-    uint32_t a = (w0 ^ (len << 27) ^ seed) * 0x85EBCA6Bu;
-    a ^= a >> 15;
-    uint32_t b = a;
-    a = (a + w1) * 0xC2B2AE35u;
-    a ^= a >> 13;
-    b = rotl32_dev(b, 11) ^ a;
-    a = (a + w2) * 0x27D4EB2Fu;
-    a ^= a >> 16;
-    b = rotl32_dev(b, 11) ^ a;
-    a = (a + w3) * 0x165667B1u;
-    a ^= a >> 15;
-    b = rotl32_dev(b, 11) + (w0 ^ rotl32_dev(w1, 8) ^ rotl32_dev(w2, 16) ^ rotl32_dev(w3, 24));
-    return ((uint64_t)b << 32) | a;
 }
 
 // Back-trace + id emission for the rows4 path: one wave per sample, 1-byte back-pointers

@@ -261,9 +261,11 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     // TGX_PATH=fused forces the one-sample-per-wave kernel (A/B timing, tests of both paths)
     const char* force = getenv("TGX_PATH");
     const bool use4 = m->lm <= 16 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
+    // vocabularies with tokens of 17..32 bytes (after `merge`): two samples per wave (encode2.hip)
+    const bool use2 = !use4 && m->lm <= 32 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
     if (debug_on())
         fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u\n",
-                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? "rows4" : "fused",
+                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? "rows4" : (use2 ? "rows2" : "fused"),
                 m->flat.table.size(), p.root_base);
     if (use4) {
         // `bpc` blocks per CU of `waves` waves each (8 KiB of LDS per wave and position group).
@@ -376,6 +378,15 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             (void)hipFree(d_tstamps);
             p.stamps = nullptr;
         }
+    } else if (use2) {
+        time_begin(m, "encode2_kernel");
+        HIP_TRY(tgx::launch_encode2(p, (uint32_t)m->num_cus, m->stream));
+        time_end(m);
+        const uint32_t blocks_t =
+            (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
+        time_begin(m, "trace32_kernel");
+        HIP_TRY(tgx::launch_trace32(p, blocks_t, m->stream));
+        time_end(m);
     } else {
         time_begin(m, "encode_kernel");
         HIP_TRY(tgx::launch_encode(p, grid_blocks(m, c->n_samples), m->stream));
@@ -472,7 +483,7 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
     HIP_TRY_M(hipMalloc(&m->d_trie, tbytes));
     HIP_TRY_M(hipMalloc((void**)&m->d_tokid, m->flat.tokid.size() * 4));
     HIP_TRY_M(hipMalloc((void**)&m->d_ctrl, 64));
-    if (m->lm <= 16 && m->scores_finite) {
+    if (m->lm <= 32 && m->scores_finite) {
         tgx::build_tok_hash(bytes, vocab_size ? offs : zero_offs, vocab_size, &m->tokhash);
         if (m->tokhash.ok) {
             const size_t hb = m->tokhash.slots.size() * sizeof(tgx::TokHashEntry);
@@ -574,9 +585,9 @@ tgx_status tgx_tok_hash_selftest(const uint8_t* bytes, const uint64_t* offs, uin
     for (uint32_t id = 0; id < vocab_size; id++) {
         const uint32_t len = (uint32_t)(offs[id + 1] - offs[id]);
         if (len == 0) continue;
-        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         memcpy(w, bytes + offs[id], len);
-        const uint64_t h = tgx::tok_hash64(w[0], w[1], w[2], w[3], len, t.seed);
+        const uint64_t h = tgx::tok_hash64_long(w, len, t.seed);
         uint32_t i = (uint32_t)h & t.mask;
         bool found = false;
         for (uint32_t probe = 0; probe <= t.mask; probe++) {  // the device loop of trace_kernel

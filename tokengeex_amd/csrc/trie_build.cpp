@@ -223,9 +223,9 @@ static bool fill_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t v
         const uint64_t b = offs[id], e = offs[id + 1];
         const uint32_t len = (uint32_t)(e - b);
         if (len == 0) continue;  // never matched
-        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         std::memcpy(w, bytes + b, len);
-        const uint64_t h = tok_hash64(w[0], w[1], w[2], w[3], len, out->seed);
+        const uint64_t h = tok_hash64_long(w, len, out->seed);
         uint32_t i = (uint32_t)h & out->mask;
         for (;;) {
             TokHashEntry& s = out->slots[i];
@@ -253,7 +253,7 @@ void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_s
     out->mask = cap - 1;
     out->ok = false;
     for (uint32_t id = 0; id < vocab_size; id++)
-        if (offs[id + 1] - offs[id] > 16) return;  // longer tokens: callers keep trie handles
+        if (offs[id + 1] - offs[id] > 32) return;  // longer tokens: callers keep trie handles
     for (uint32_t attempt = 0; attempt < 8 && !out->ok; attempt++) {
         out->seed = attempt * 0x9E3779B1u;
         out->ok = fill_tok_hash(bytes, offs, vocab_size, out);

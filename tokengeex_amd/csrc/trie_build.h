@@ -41,7 +41,7 @@ struct FlatTrie {
 void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                      uint32_t vocab_size, FlatTrie* out);
 
-// Token-bytes -> id hash table (tokens of 1..16 bytes): lets the trace kernel turn a
+// Token-bytes -> id hash table (tokens of 1..32 bytes): lets the trace kernel turn a
 // (start, length) pair straight into a token id with one probe instead of carrying a trie
 // handle through the DP.  Open addressing, linear probing, capacity a power of two >= 2V;
 // entry = {hash64 of the bytes, id, used}.  The 64-bit hash is verified to be collision-free
@@ -76,6 +76,26 @@ inline uint64_t tok_hash64(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, u
     a = (a + w3) * 0x165667B1u;
     a ^= a >> 15;
     b = tok_rotl32(b, 11) + (w0 ^ tok_rotl32(w1, 8) ^ tok_rotl32(w2, 16) ^ tok_rotl32(w3, 24));
+    return ((uint64_t)b << 32) | a;
+}
+// tok_hash64 continued over four more dwords for tokens of 17..32 bytes (eight zero-padded dwords);
+// equal to tok_hash64 for len <= 16
+inline uint64_t tok_hash64_long(const uint32_t* w, uint32_t len, uint32_t seed) {
+    const uint64_t h = tok_hash64(w[0], w[1], w[2], w[3], len, seed);
+    if (len <= 16) return h;
+    uint32_t a = (uint32_t)h, b = (uint32_t)(h >> 32);
+    a = (a + w[4]) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    b = tok_rotl32(b, 11) ^ a;
+    a = (a + w[5]) * 0xC2B2AE35u;
+    a ^= a >> 13;
+    b = tok_rotl32(b, 11) ^ a;
+    a = (a + w[6]) * 0x27D4EB2Fu;
+    a ^= a >> 16;
+    b = tok_rotl32(b, 11) ^ a;
+    a = (a + w[7]) * 0x165667B1u;
+    a ^= a >> 15;
+    b = tok_rotl32(b, 11) + (w[4] ^ tok_rotl32(w[5], 8) ^ tok_rotl32(w[6], 16) ^ tok_rotl32(w[7], 24));
     return ((uint64_t)b << 32) | a;
 }
 void build_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out);
