@@ -150,6 +150,11 @@ tgx_status tgx_count_tokens(tgx_model *m, tgx_corpus *c, uint64_t *freq);
  * Returns malloc'd arrays sorted by key = (a << 32) | b; free with tgx_free. */
 tgx_status tgx_count_pairs(tgx_model *m, tgx_corpus *c, uint64_t **keys, uint64_t **counts,
                            uint64_t *n_pairs);
+/* The same scan, but only the max_pairs MOST FREQUENT pairs come back, ordered by descending count and
+ * ascending key among equal counts — the order in which the merge loop consumes them (src/merge.rs:84-126);
+ * *n_total = number of distinct pairs.  Saves the copy and the host sort of a table of millions. */
+tgx_status tgx_count_pairs_top(tgx_model *m, tgx_corpus *c, uint64_t max_pairs, uint64_t **keys,
+                               uint64_t **counts, uint64_t *n_pairs, uint64_t *n_total);
 
 /* run_e_step — src/prune.rs:64-120 over src/model.rs:34-55 + src/lattice.rs:245-333:
  * each sample cut into <= snippet_len-byte snippets, forward/backward in f64

@@ -220,3 +220,20 @@ def test_estep_every_positions_per_lane_variant(monkeypatch, eppl):
     texts = [b"", b"a", b"ab" * 8, b"ab" * 8 + b"c", b"xyz" * 21 + b"x", b"q" * 64, b"q" * 65, b"hello world " * 30]
     f2, o2 = tgx.pack(texts)
     _check_estep(nat, ora, f2, o2, snippet_len=48, dropout=0.0, seed=0)
+
+
+def test_count_pairs_top_is_the_head_of_the_full_table():
+    """tgx_count_pairs_top: the k most frequent pairs by descending count, ascending key among equal counts."""
+    flat, offs, toks, scores = corpus_and_vocab(1 << 20, "mixed", 3000, 16, seed_offset=31)
+    nat, _ = _pair(toks, scores)
+    corpus = tgx.NativeCorpus(flat, offs)
+    keys, counts = nat.count_pairs(corpus)
+    order = np.lexsort((keys, -counts.astype(np.int64)))
+    for k in (1, 100, 5000, keys.size, keys.size + 10):
+        tk, tc, total = nat.count_pairs_top(corpus, k)
+        assert total == keys.size and tk.size == min(k, keys.size)
+        np.testing.assert_array_equal(tk, keys[order[:tk.size]])
+        np.testing.assert_array_equal(tc, counts[order[:tk.size]])
+    e_flat, e_offs = tgx.pack([b"", b"a"])
+    tk, tc, total = nat.count_pairs_top(tgx.NativeCorpus(e_flat, e_offs), 10)   # no pair at all
+    assert tk.size == 0 and total == 0

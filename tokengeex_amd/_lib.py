@@ -57,6 +57,7 @@ SYMBOLS = {
     "tgx_encode_corpus": (_i, [_vp, _vp, _d, _u64, _pvp]),
     "tgx_count_tokens": (_i, [_vp, _vp, _vp]),
     "tgx_count_pairs": (_i, [_vp, _vp, _pvp, _pvp, _pu64]),
+    "tgx_count_pairs_top": (_i, [_vp, _vp, _u64, _pvp, _pvp, _pu64, _pu64]),
     "tgx_estep": (_i, [_vp, _vp, _u64, _d, _u64, _vp, C.POINTER(C.c_double)]),
     "tgx_free": (None, [_vp]),
     "tgx_digamma": (_d, [_d]),
@@ -260,6 +261,18 @@ class NativeModel:
         lib.tgx_free(keys)
         lib.tgx_free(counts)
         return ka, ca
+
+    def count_pairs_top(self, corpus: NativeCorpus, max_pairs: int) -> tuple[np.ndarray, np.ndarray, int]:
+        """The max_pairs most frequent pairs, by descending count then ascending key -> (keys, counts, n_total)."""
+        keys, counts, n, tot = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        check(lib.tgx_count_pairs_top(self._h, corpus._h, int(max_pairs), C.byref(keys), C.byref(counts),
+                                      C.byref(n), C.byref(tot)))
+        k = n.value
+        ka = np.ctypeslib.as_array(C.cast(keys, C.POINTER(C.c_uint64)), shape=(max(k, 1),))[:k].copy()
+        ca = np.ctypeslib.as_array(C.cast(counts, C.POINTER(C.c_uint64)), shape=(max(k, 1),))[:k].copy()
+        lib.tgx_free(keys)
+        lib.tgx_free(counts)
+        return ka, ca, tot.value
 
     def estep(self, corpus: NativeCorpus, snippet_len: int = ESTEP_SNIPPET_LEN, dropout: float = 0.0,
               seed: int = 0, expected: np.ndarray | None = None) -> tuple[np.ndarray, float]:

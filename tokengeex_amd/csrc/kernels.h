@@ -69,6 +69,10 @@ hipError_t pair_rle(void* temp, size_t temp_bytes, const unsigned long long* sor
                     unsigned long long* unique_out, unsigned int* counts_out, unsigned int* n_runs_out,
                     hipStream_t stream);
 
+hipError_t pair_count_sort_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t pair_count_sort(void* temp, size_t temp_bytes, const unsigned int* counts_in, unsigned int* counts_out,
+                           const unsigned long long* keys_in, unsigned long long* keys_out, uint64_t n,
+                           hipStream_t stream);
 hipError_t ids_sort_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t ids_sort(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint64_t n,
                     unsigned int end_bit, hipStream_t stream);

@@ -70,6 +70,23 @@ hipError_t pair_rle(void* temp, size_t temp_bytes, const unsigned long long* sor
 
 // ---- token histogram (frequency pass, src/prune.rs:205-244) by sort + run-length encode:
 // global atomics on a Zipf-distributed id stream serialise on the hot tokens.
+// (unique key, count) table ordered by count descending; the sort is stable, so equal counts keep the
+// ascending key order of the input
+hipError_t pair_count_sort_temp_bytes(uint64_t n, size_t* bytes) {
+    unsigned int* c = nullptr;
+    unsigned long long* k = nullptr;
+    size_t b = 0;
+    hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, b, c, c, k, k, (size_t)n);
+    *bytes = b;
+    return e;
+}
+hipError_t pair_count_sort(void* temp, size_t temp_bytes, const unsigned int* counts_in, unsigned int* counts_out,
+                           const unsigned long long* keys_in, unsigned long long* keys_out, uint64_t n,
+                           hipStream_t stream) {
+    return rocprim::radix_sort_pairs_desc(temp, temp_bytes, counts_in, counts_out, keys_in, keys_out, (size_t)n, 0, 32,
+                                          stream);
+}
+
 hipError_t ids_sort_temp_bytes(uint64_t n, size_t* bytes) {
     uint32_t* p = nullptr;
     size_t b = 0;

@@ -878,11 +878,14 @@ tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
     return cleanup(TGX_OK);
 }
 
-tgx_status tgx_count_pairs(tgx_model* m, tgx_corpus* c, uint64_t** keys, uint64_t** counts,
-                           uint64_t* n_pairs) {
+// max_pairs == 0: the whole table in ascending key order (tgx_count_pairs); otherwise the max_pairs most
+// frequent pairs, by descending count and ascending key among equal counts (tgx_count_pairs_top)
+static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pairs, uint64_t** keys, uint64_t** counts,
+                                   uint64_t* n_pairs, uint64_t* n_total) {
     if (!m || !c || !keys || !counts || !n_pairs) return fail(TGX_ERR_INVALID, "tgx_count_pairs: NULL argument");
     *keys = *counts = nullptr;
     *n_pairs = 0;
+    if (n_total) *n_total = 0;
     if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
     std::lock_guard<std::mutex> lk(m->mu);
     tgx_result* r = nullptr;
@@ -932,12 +935,39 @@ tgx_status tgx_count_pairs(tgx_model* m, tgx_corpus* c, uint64_t** keys, uint64_
     if (hipMemcpyAsync(&runs, d_runs, 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipStreamSynchronize(m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "pair scan failed: %s", hipGetErrorString(hipGetLastError())));
+    // the sentinel run (one per non-empty sample) has the largest key: it is the last run
+    unsigned long long last_key = 0;
+    if (runs && hipMemcpy(&last_key, d_unique + (runs - 1), 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "D2H copy failed"));
+    if (runs && last_key == ~0ULL) runs--;
+    const unsigned long long* src_keys = d_unique;
+    const unsigned int* src_cnt = d_cnt;
+    if (n_total) *n_total = runs;
+    if (max_pairs && runs) {
+        // order by count on the device and hand back the head only: the merge loop looks at a few hundred
+        // candidates of a table of millions (src/merge.rs:84-126)
+        size_t tb3 = 0;
+        if (tgx::pair_count_sort_temp_bytes(runs, &tb3) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "rocPRIM temp-size query failed"));
+        void* d_temp3 = nullptr;
+        if (pool_alloc(m->device, tb3 + 256, &d_temp3) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (pair scan)"));
+        unsigned int* cnt_out = reinterpret_cast<unsigned int*>(d_sorted);  // the sorted keys are no longer needed
+        time_begin(m, "pair_count_sort");
+        hipError_t e3 = tgx::pair_count_sort(d_temp3, tb3, d_cnt, cnt_out, d_unique, d_keys, runs, m->stream);
+        time_end(m);
+        if (e3 == hipSuccess) e3 = hipStreamSynchronize(m->stream);
+        pool_free(m->device, d_temp3, tb3 + 256);
+        if (e3 != hipSuccess) return cleanup(fail(TGX_ERR_DEVICE, "pair count sort failed"));
+        src_keys = d_keys;
+        src_cnt = cnt_out;
+        runs = (unsigned int)std::min<uint64_t>(runs, max_pairs);
+    }
     std::vector<unsigned long long> hk(runs ? runs : 1);
     std::vector<unsigned int> hc(runs ? runs : 1);
-    if (runs && (hipMemcpy(hk.data(), d_unique, (size_t)runs * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                 hipMemcpy(hc.data(), d_cnt, (size_t)runs * 4, hipMemcpyDeviceToHost) != hipSuccess))
+    if (runs && (hipMemcpy(hk.data(), src_keys, (size_t)runs * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                 hipMemcpy(hc.data(), src_cnt, (size_t)runs * 4, hipMemcpyDeviceToHost) != hipSuccess))
         return cleanup(fail(TGX_ERR_DEVICE, "D2H copy of pair table failed"));
-    if (runs && hk[runs - 1] == ~0ULL) runs--;  // the sentinel run (one per non-empty sample) sorts last
     uint64_t* ok = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
     uint64_t* oc = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
     for (unsigned int i = 0; i < runs; i++) {
@@ -950,6 +980,16 @@ tgx_status tgx_count_pairs(tgx_model* m, tgx_corpus* c, uint64_t** keys, uint64_
     // N + 8(S+1) + 16P
     m->last_alg_bytes = c->n_bytes + 8 * (S + 1) + 16ull * runs;
     return cleanup(TGX_OK);
+}
+
+tgx_status tgx_count_pairs(tgx_model* m, tgx_corpus* c, uint64_t** keys, uint64_t** counts, uint64_t* n_pairs) {
+    return count_pairs_impl(m, c, 0, keys, counts, n_pairs, nullptr);
+}
+
+tgx_status tgx_count_pairs_top(tgx_model* m, tgx_corpus* c, uint64_t max_pairs, uint64_t** keys, uint64_t** counts,
+                               uint64_t* n_pairs, uint64_t* n_total) {
+    if (max_pairs == 0) return fail(TGX_ERR_INVALID, "tgx_count_pairs_top: max_pairs must be positive");
+    return count_pairs_impl(m, c, max_pairs, keys, counts, n_pairs, n_total);
 }
 
 // Builds (once) the double-array of the REVERSED tokens used by the backward sweep.

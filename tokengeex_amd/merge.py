@@ -85,6 +85,7 @@ class ModelVocabularyMerger:
         # multi-GPU: one process per GPU with its own shard; the per-rank pair tables are merged on every
         # rank (dist.allreduce_pairs), so all ranks pick the same merges
         self.dist, self.reduce_device = dist, reduce_device
+        self.head_pairs = 1 << 18  # pairs fetched per round in single-process mode
         self.rounds: list[dict] = []
 
     def select(self, vocab, keys: np.ndarray, counts: np.ndarray, budget: int, ignore: set):
@@ -117,10 +118,18 @@ class ModelVocabularyMerger:
             while len(vocab) < start + self.num_merges:
                 model = _lib.NativeModel([t[0] for t in vocab], [t[1] for t in vocab], self.device)
                 t0 = time.perf_counter()
-                keys, counts = tdist.allreduce_pairs(*model.count_pairs(corpus), self.dist, self.reduce_device)
+                single = self.dist is None or not self.dist.is_initialized() or self.dist.get_world_size() == 1
+                budget = min(self.step, self.num_merges - (len(vocab) - start))
+                if single:
+                    # the head of the table, ordered on the device (tgx_count_pairs_top): the loop below looks at a
+                    # few hundred candidates of millions of pairs; the whole table only if the head runs dry
+                    keys, counts, total = model.count_pairs_top(corpus, self.head_pairs)
+                    if keys.size < total and len(self.select(vocab, keys, counts, budget, set(ignore))) < budget:
+                        keys, counts = model.count_pairs(corpus)
+                else:
+                    keys, counts = tdist.allreduce_pairs(*model.count_pairs(corpus), self.dist, self.reduce_device)
                 t1 = time.perf_counter()
                 model.free()
-                budget = min(self.step, self.num_merges - (len(vocab) - start))
                 new = self.select(vocab, keys, counts, budget, ignore)
                 vocab.extend(new)  # model.add_tokens, src/merge.rs:121
                 self.rounds.append({"vocab": len(vocab), "pairs": int(keys.size), "merged": len(new),
