@@ -75,6 +75,12 @@ int tgx_device_count(void);
  * = build a new handle (as `*model = Model::from(vocab)`, src/prune.rs:48,53). */
 tgx_status tgx_model_create(const uint8_t *bytes, const uint64_t *offs, const double *scores,
                             uint32_t vocab_size, int device, tgx_model **out);
+/* As tgx_model_create; flags: TGX_MODEL_FOR_ESTEP builds the tables of the E-step's backward sweep on a second
+ * host thread during creation instead of at the first tgx_estep call (Model::from is rebuilt for every EM
+ * sub-iteration, src/prune.rs:48). */
+#define TGX_MODEL_FOR_ESTEP 1u
+tgx_status tgx_model_create_ex(const uint8_t *bytes, const uint64_t *offs, const double *scores,
+                               uint32_t vocab_size, int device, uint32_t flags, tgx_model **out);
 void tgx_model_destroy(tgx_model *m);
 uint32_t tgx_model_vocab_size(const tgx_model *m);     /* Model::vocab_size, src/model.rs:179 */
 uint32_t tgx_model_max_token_len(const tgx_model *m);

@@ -29,6 +29,7 @@ SYMBOLS = {
     "tgx_abi_version": (_i, []),
     "tgx_device_count": (_i, []),
     "tgx_model_create": (_i, [_vp, _vp, _vp, _u32, _i, _pvp]),
+    "tgx_model_create_ex": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _pvp]),
     "tgx_model_destroy": (None, [_vp]),
     "tgx_model_vocab_size": (_u32, [_vp]),
     "tgx_model_max_token_len": (_u32, [_vp]),
@@ -200,14 +201,14 @@ class NativeCorpus:
 class NativeModel:
     """Owns a tgx_model: Model::from(vocab) flattened into HBM (src/model.rs:16-30)."""
 
-    def __init__(self, tokens: list[bytes], scores, device: int = 0):
+    def __init__(self, tokens: list[bytes], scores, device: int = 0, for_estep: bool = False):
         flat, offs = pack(tokens)
         self._scores = np.ascontiguousarray(scores, dtype=np.float64)
         if self._scores.shape[0] != len(tokens):
             raise ValueError("scores and tokens differ in length")
         h = C.c_void_p()
-        check(lib.tgx_model_create(ptr(flat) if flat.size else None, ptr(offs), ptr(self._scores),
-                                   len(tokens), device, C.byref(h)))
+        check(lib.tgx_model_create_ex(ptr(flat) if flat.size else None, ptr(offs), ptr(self._scores),
+                                      len(tokens), device, 1 if for_estep else 0, C.byref(h)))
         self._h = h
         self.device = device
 

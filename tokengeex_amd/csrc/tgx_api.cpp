@@ -13,6 +13,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tgx.h"
@@ -125,6 +126,7 @@ struct tgx_model {
     std::vector<double> vocab_scores;
     tgx::FlatTrie flat_rev;
     void* d_trie_rev = nullptr;
+    bool rev_host_built = false;    // flat_rev was built at creation (TGX_MODEL_FOR_ESTEP)
     void* d_trie_w = nullptr;       // forward / reversed tables with w = exp(score) in place of the score
     void* d_trie_rev_w = nullptr;   //   (linear-domain E-step, estep4l.hip)
     int last_encode_waves_per_cu = 0;  // resident waves per CU of the last rows4 encode launch (self-check)
@@ -428,6 +430,11 @@ void tgx_free(void* p) { free(p); }
 
 tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                             uint32_t vocab_size, int device, tgx_model** out) {
+    return tgx_model_create_ex(bytes, offs, scores, vocab_size, device, 0, out);
+}
+
+tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const double* scores,
+                               uint32_t vocab_size, int device, uint32_t flags, tgx_model** out) {
     if (!out) return fail(TGX_ERR_INVALID, "tgx_model_create: out is NULL");
     *out = nullptr;
     if (vocab_size && (!offs || !scores)) return fail(TGX_ERR_INVALID, "tgx_model_create: NULL vocab");
@@ -440,7 +447,25 @@ tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const do
     m->device = device;
     m->vocab_size = vocab_size;
     static const uint64_t zero_offs[1] = {0};
+    // TGX_MODEL_FOR_ESTEP: the double-array of the REVERSED tokens (backward sweep of the E-step) is built
+    // on a second host thread while this one builds the forward table — `prune` makes a new model for every
+    // EM sub-iteration (src/prune.rs:48), and at 500 K tokens each table takes ~0.4 s of host time
+    std::thread rev_builder;
+    if ((flags & TGX_MODEL_FOR_ESTEP) && vocab_size)
+        rev_builder = std::thread([m, bytes, offs, scores, vocab_size]() {
+            const uint64_t o0 = offs[0];
+            std::vector<uint8_t> rev((size_t)(offs[vocab_size] - o0));
+            std::vector<uint64_t> ro(vocab_size + 1);
+            for (uint32_t i = 0; i <= vocab_size; i++) ro[i] = offs[i] - o0;
+            for (uint32_t i = 0; i < vocab_size; i++)
+                for (uint64_t k = ro[i]; k < ro[i + 1]; k++) rev[k] = bytes[o0 + ro[i + 1] - 1 - (k - ro[i])];
+            tgx::build_flat_trie(rev.data(), ro.data(), scores, vocab_size, &m->flat_rev);
+        });
     tgx::build_flat_trie(bytes, vocab_size ? offs : zero_offs, scores, vocab_size, &m->flat);
+    if (rev_builder.joinable()) {
+        rev_builder.join();
+        m->rev_host_built = true;
+    }
     if (m->flat.max_token_len > TGX_MAX_TOKEN_LEN) {
         uint32_t l = m->flat.max_token_len;
         delete m;
@@ -996,12 +1021,14 @@ tgx_status tgx_count_pairs_top(tgx_model* m, tgx_corpus* c, uint64_t max_pairs, 
 static tgx_status ensure_reverse_trie(tgx_model* m) {
     if (m->d_trie_rev) return TGX_OK;
     const uint32_t V = m->vocab_size;
-    std::vector<uint8_t> rev(m->vocab_bytes.size());
-    for (uint32_t i = 0; i < V; i++) {
-        const uint64_t b = m->vocab_offs[i], e = m->vocab_offs[i + 1];
-        for (uint64_t k = b; k < e; k++) rev[k] = m->vocab_bytes[e - 1 - (k - b)];
+    if (!m->rev_host_built) {
+        std::vector<uint8_t> rev(m->vocab_bytes.size());
+        for (uint32_t i = 0; i < V; i++) {
+            const uint64_t b = m->vocab_offs[i], e = m->vocab_offs[i + 1];
+            for (uint64_t k = b; k < e; k++) rev[k] = m->vocab_bytes[e - 1 - (k - b)];
+        }
+        tgx::build_flat_trie(rev.data(), m->vocab_offs.data(), m->vocab_scores.data(), V, &m->flat_rev);
     }
-    tgx::build_flat_trie(rev.data(), m->vocab_offs.data(), m->vocab_scores.data(), V, &m->flat_rev);
     if (m->flat_rev.table.size() >= (1u << 26)) return fail(TGX_ERR_UNSUPPORTED, "reversed trie needs more than 2^26 slots");
     HIP_TRY(hipSetDevice(m->device));
     const size_t tbytes = m->flat_rev.table.size() * sizeof(tgx::TrieRec);

@@ -140,14 +140,15 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     ba.add_block();
     ba.mark(0);  // root
     std::vector<uint32_t> slot(n_nodes, 0), base(n_nodes, 0);
-    auto colder = [&weight](uint32_t a, uint32_t b) {
-        return weight[a] != weight[b] ? weight[a] < weight[b] : a > b;
-    };
-    std::priority_queue<uint32_t, std::vector<uint32_t>, decltype(colder)> queue(colder);
-    queue.push(0);
-    while (!queue.empty()) {
-        uint32_t node = queue.top();
-        queue.pop();
+    // Expansion order: descending weight, the older node first among equals.  A parent weighs at least as
+    // much as any of its children and was created before them, so one sort gives an order in which every
+    // node comes after its parent (the order a priority queue over the frontier would pop them in).
+    std::vector<uint32_t> expand(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) expand[i] = i;
+    std::sort(expand.begin(), expand.end(), [&weight](uint32_t a, uint32_t b) {
+        return weight[a] != weight[b] ? weight[a] > weight[b] : a < b;
+    });
+    for (uint32_t node : expand) {
         uint32_t lo = row[node], hi = row[node + 1], k = hi - lo;
         if (k == 0) continue;
         uint32_t chosen = 0;
@@ -192,7 +193,6 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
             uint32_t t = chosen ^ edges[j].byte;
             ba.mark(t);
             slot[edges[j].child] = t;
-            queue.push(edges[j].child);
         }
     }
 

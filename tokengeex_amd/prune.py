@@ -38,8 +38,8 @@ class ModelVocabularyPruner:
         self.timings: list[dict] = []
 
     # -- one pass each ------------------------------------------------------------------
-    def _model(self, vocab: Vocab) -> _lib.NativeModel:
-        return _lib.NativeModel([t[0] for t in vocab], [t[1] for t in vocab], self.device)
+    def _model(self, vocab: Vocab, for_estep: bool = False) -> _lib.NativeModel:
+        return _lib.NativeModel([t[0] for t in vocab], [t[1] for t in vocab], self.device, for_estep=for_estep)
 
     def run_e_step(self, model: _lib.NativeModel, corpus: _lib.NativeCorpus) -> np.ndarray:
         """src/prune.rs:64-120 (81 920-byte snippets; z must be normal)."""
@@ -76,7 +76,7 @@ class ModelVocabularyPruner:
             while len(vocab) > self.vocab_size:
                 rec = {"from": len(vocab), "e_step_s": 0.0, "m_step_s": 0.0}
                 for sub in range(self.em_subiters):
-                    model = self._model(vocab)
+                    model = self._model(vocab, for_estep=True)
                     t0 = time.perf_counter()
                     expected = self.run_e_step(model, corpus)
                     t1 = time.perf_counter()
