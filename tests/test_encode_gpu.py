@@ -240,19 +240,37 @@ def test_every_positions_per_lane_variant(monkeypatch, ppl):
     assert_same_encoding(nat, ora, f2, o2)
 
 
+@pytest.mark.parametrize("path", ["default", "rows2"])
 @pytest.mark.parametrize("max_len", [17, 20, 24, 32])
-def test_two_samples_per_wave_path_for_long_tokens(max_len):
-    """Vocabularies whose longest token has 17..32 bytes (after `merge`) take encode2_kernel + trace32_kernel:
-    bit-exact against the oracle incl. dropout, block-boundary lengths and unreachable ends."""
+def test_long_token_vocabularies(monkeypatch, max_len, path):
+    """Vocabularies whose longest token has 17..32 bytes (after `merge`): encode4l_kernel (16-lane rows with an
+    overflow list for the long matches) by default, encode2_kernel (two samples per wave) with TGX_PATH=rows2;
+    both bit-exact against the oracle incl. dropout, ties, block-boundary lengths and unreachable ends."""
+    if path == "rows2":
+        monkeypatch.setenv("TGX_PATH", "rows2")
     rng = np.random.default_rng(4000 + max_len)
     flat, offs = synth.make_corpus(384 << 10, "mixed", seed_offset=50 + max_len, max_len=20000)
-    toks, scores = synth.random_vocab(rng, bytes(flat[: 96 << 10]), n_multi=4000, max_len=max_len)
+    toks, scores = synth.random_vocab(rng, bytes(flat[: 96 << 10]), n_multi=4000, max_len=max_len, tie_fraction=0.5)
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
     assert 16 < nat.max_token_len <= max_len
     assert_same_encoding(nat, ora, flat, offs)
-    assert "encode2_kernel" in nat.last_kernel_times() and "trace32_kernel" in nat.last_kernel_times()
+    kt = nat.last_kernel_times()
+    assert ("encode2_kernel" if path == "rows2" else "encode4l_kernel") in kt and "trace32_kernel" in kt
     assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=9)
     longest = max(toks, key=len)
     texts = [b"", b"a", longest, longest * 3, b"ab" * 16, b"ab" * 16 + b"a", b"ab" * 32, b"q" * 31, b"q" * 33, b"hello world " * 40]
     f2, o2 = tgx.pack(texts)
     assert_same_encoding(nat, ora, f2, o2)
+
+
+def test_long_token_overflow_falls_back_to_two_samples_per_wave():
+    """Every position of "aaaa..." matches sixteen tokens of 17..32 bytes: far more than a wave's overflow list
+    holds, so the pass is redone by encode2_kernel; ties everywhere (scores proportional to length)."""
+    toks = [bytes([c]) for c in range(256)] + [b"a" * k for k in range(2, 33)]
+    scores = np.array([-3.0] * 256 + [-3.0 * k for k in range(2, 33)])   # a^k scores like k single a's: ties
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    texts = [b"a" * 700, b"a" * 33 + b"b" + b"a" * 64, b"xyz", b"a" * 17]
+    flat, offs = tgx.pack(texts)
+    assert_same_encoding(nat, ora, flat, offs)
+    kt = nat.last_kernel_times()
+    assert "encode4l_kernel" in kt and "encode2_kernel" in kt

@@ -230,6 +230,8 @@ __device__ __forceinline__ uint64_t tok_hash64_long_dev(const uint32_t* w, uint3
 
 // trace_kernel (kernels.hip) for tokens of up to 32 bytes: one wave per sample, plain 1-byte back-pointers
 // (token length - 1, 0..31), ids recovered from the token's bytes through the hash table.
+// PERM: the back-pointer bytes are in encode4_kernel's permuted layout (bp8_perm; encode4l_kernel), else plain
+template <bool PERM>
 __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wpb = blockDim.x >> 6;
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
         auto window_loads = [&](uint32_t wq, uint32_t& hraw, uint32_t& traw) {
             const uint32_t a0 = wq >= 32u ? wq - 32u : 0u;
             const uint32_t* __restrict__ gw = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + a0) & ~uintptr_t(3));
-            hraw = (wq + lane < n) ? (uint32_t)bp[wq + lane] : 0u;
+            hraw = (wq + lane < n) ? (uint32_t)bp[PERM ? bp8_perm(wq + lane) : wq + lane] : 0u;
             traw = (lane <= 24u) ? gw[lane] : 0u;
         };
         uint32_t h_cur = 0, t_cur = 0;
@@ -335,8 +337,11 @@ hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, hipStream_t s
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * waves), waves * kRows2Bytes, stream, p);
     return hipGetLastError();
 }
-hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(trace32_kernel, dim3(blocks), dim3(256), 0, stream, p);
+hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream) {
+    if (permuted)
+        hipLaunchKernelGGL(trace32_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(trace32_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

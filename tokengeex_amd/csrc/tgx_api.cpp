@@ -381,14 +381,36 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             p.stamps = nullptr;
         }
     } else if (use2) {
-        time_begin(m, "encode2_kernel");
-        HIP_TRY(tgx::launch_encode2(p, (uint32_t)m->num_cus, m->stream));
-        time_end(m);
+        // Tokens of 17..32 bytes: the 16-lane rows with an overflow list for the long matches (encode4l.hip);
+        // if some wave's list filled up, or with TGX_PATH=rows2, two samples per wave on 32-lane rows.
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
-        time_begin(m, "trace32_kernel");
-        HIP_TRY(tgx::launch_trace32(p, blocks_t, m->stream));
-        time_end(m);
+        bool rows2 = force && strcmp(force, "rows2") == 0;
+        if (!rows2) {
+            p.ovf_flag = m->d_ctrl + 6;
+            HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
+            time_begin(m, "encode4l_kernel");
+            HIP_TRY(tgx::launch_encode4l(p, (uint32_t)m->num_cus, m->stream));
+            time_end(m);
+            unsigned long long flag = 0;
+            HIP_TRY(hipMemcpyAsync(&flag, m->d_ctrl + 6, 8, hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            rows2 = flag != 0;
+            if (!rows2) {
+                time_begin(m, "trace32_kernel");
+                HIP_TRY(tgx::launch_trace32(p, blocks_t, true, m->stream));
+                time_end(m);
+            }
+        }
+        if (rows2) {
+            HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
+            time_begin(m, "encode2_kernel");
+            HIP_TRY(tgx::launch_encode2(p, (uint32_t)m->num_cus, m->stream));
+            time_end(m);
+            time_begin(m, "trace32_kernel");
+            HIP_TRY(tgx::launch_trace32(p, blocks_t, false, m->stream));
+            time_end(m);
+        }
     } else {
         time_begin(m, "encode_kernel");
         HIP_TRY(tgx::launch_encode(p, grid_blocks(m, c->n_samples), m->stream));
