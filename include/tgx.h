@@ -201,6 +201,9 @@ uint64_t tgx_last_algorithmic_bytes(const tgx_model *m);
 /* waves per CU the last four-samples-per-wave encode launch really had resident (occupancy query for
  * its kernel variant, block size and LDS): a self-check that the launch geometry fits the device. */
 uint32_t tgx_last_encode_waves_per_cu(const tgx_model *m);
+/* samples the last encode of a vocabulary with tokens of 17..32 bytes had to redo with the
+ * two-samples-per-wave kernel because a wave ran out of overflow entries for long matches (0 = none). */
+uint64_t tgx_last_encode_redo_samples(const tgx_model *m);
 
 /* ---- dropout ---------------------------------------------------------------
  * The reference draws rand::random::<f64>() from an unseeded thread RNG

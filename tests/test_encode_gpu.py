@@ -263,14 +263,26 @@ def test_long_token_vocabularies(monkeypatch, max_len, path):
     assert_same_encoding(nat, ora, f2, o2)
 
 
-def test_long_token_overflow_falls_back_to_two_samples_per_wave():
+def test_long_token_overflow_redoes_only_the_samples_concerned():
     """Every position of "aaaa..." matches sixteen tokens of 17..32 bytes: far more than a wave's overflow list
-    holds, so the pass is redone by encode2_kernel; ties everywhere (scores proportional to length)."""
+    holds, so the samples of such a wave are redone by encode2_kernel (and only those: the batch also has
+    hundreds of samples without a long match); ties everywhere (scores proportional to length)."""
     toks = [bytes([c]) for c in range(256)] + [b"a" * k for k in range(2, 33)]
     scores = np.array([-3.0] * 256 + [-3.0 * k for k in range(2, 33)])   # a^k scores like k single a's: ties
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
-    texts = [b"a" * 700, b"a" * 33 + b"b" + b"a" * 64, b"xyz", b"a" * 17]
+    rng = np.random.default_rng(11)
+    plain = [bytes(rng.integers(98, 123, size=int(rng.integers(1, 400)), dtype=np.uint8)) for _ in range(600)]
+    texts = [b"a" * 700, b"a" * 33 + b"b" + b"a" * 64, b"xyz", b"a" * 17] + plain + [b"q" * 50 + b"a" * 90]
     flat, offs = tgx.pack(texts)
     assert_same_encoding(nat, ora, flat, offs)
     kt = nat.last_kernel_times()
     assert "encode4l_kernel" in kt and "encode2_kernel" in kt
+    # the three samples with long runs of "a" and at most the three others of each of their waves
+    assert 3 <= nat.last_encode_redo_samples() <= 12
+    # dropout: the redone samples draw the same per-(sample, position, length) numbers in either kernel
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=5)
+    assert nat.last_encode_redo_samples() >= 1
+    # a batch without long matches leaves nothing to redo
+    f2, o2 = tgx.pack(plain)
+    assert_same_encoding(nat, ora, f2, o2)
+    assert nat.last_encode_redo_samples() == 0 and "encode2_kernel" not in nat.last_kernel_times()

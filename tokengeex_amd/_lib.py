@@ -68,6 +68,7 @@ SYMBOLS = {
     "tgx_last_kernel_times": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i]),
     "tgx_last_algorithmic_bytes": (_u64, [_vp]),
     "tgx_last_encode_waves_per_cu": (_u32, [_vp]),
+    "tgx_last_encode_redo_samples": (_u64, [_vp]),
 }
 
 
@@ -305,6 +306,9 @@ class NativeModel:
 
     def last_encode_waves_per_cu(self) -> int:
         return lib.tgx_last_encode_waves_per_cu(self._h)
+
+    def last_encode_redo_samples(self) -> int:
+        return lib.tgx_last_encode_redo_samples(self._h)
 
 
 class FlatTrie:

@@ -35,7 +35,8 @@ __device__ __forceinline__ void relax2_step(double sv, double& acc, uint32_t& bp
     bpv = sel_imm_u32<U>(take, bpv);
 }
 
-template <bool DROPOUT>
+// PERM: back-pointer bytes in encode4_kernel's permuted layout (the samples encode4l_kernel left to this kernel)
+template <bool DROPOUT, bool PERM>
 __global__ __launch_bounds__(640) void encode2_kernel(EncodeParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 32;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(640) void encode2_kernel(EncodeParams P) {
         if (live && pg >= 1u && pg <= n) {
             // winner pushed at step U = fin into lane l: token length ((l - U - 1) & 31) + 1
             const uint8_t b = reached ? (uint8_t)((l - fin - 1u) & 31u) : (uint8_t)0xFF;
-            __builtin_nontemporal_store(b, P.bp8 + bp8_base(beg, s) + pg - 1);
+            __builtin_nontemporal_store(b, P.bp8 + bp8_base(beg, s) + (PERM ? bp8_perm(pg - 1u) : pg - 1u));
         }
         if (live) {
             const uint32_t left = n - p0;
@@ -327,11 +328,12 @@ __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
 }
 
 // two blocks of five waves per CU: 10 x 16 KiB of LDS
-hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, hipStream_t stream) {
+hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream) {
     const uint32_t waves = 5, bpc = 2;
     const uint64_t want = (p.n_samples + 2 * waves - 1) / (2 * waves);
     const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus * bpc ? (want ? want : 1) : (uint64_t)num_cus * bpc);
-    auto fn = p.dropout > 0.0 ? encode2_kernel<true> : encode2_kernel<false>;
+    auto fn = p.dropout > 0.0 ? (permuted ? encode2_kernel<true, true> : encode2_kernel<true, false>)
+                              : (permuted ? encode2_kernel<false, true> : encode2_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * waves), waves * kRows2Bytes, stream, p);

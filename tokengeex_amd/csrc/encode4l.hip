@@ -18,8 +18,9 @@
 // an equal score iff its token is longer than the current winner's (and `far` wins ties against near
 // candidates when a lane restarts: everything in `far` starts earlier than any near start of that position).
 //
-// An overflow list that fills up (kOvfCap entries per wave and block) raises P.ovf_flag: the host then redoes
-// the pass with the two-samples-per-wave kernel (encode2.hip), which has no such limit.
+// An overflow list that fills up (kOvfCap entries per wave and block; e.g. a run of blanks when the vocabulary
+// has several long blank tokens) puts the wave's current samples on P.redo_list: the host then redoes exactly
+// those samples with the two-samples-per-wave kernel (encode2.hip), which has no such limit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(512, 4) void encode4l_kernel(EncodeParams P) {  // 
     for (int q = 0; q < 9; ++q) wn[q] = 0;
     uint32_t pk = 0, pk_j = 0;
     bool pk_dirty = false;
+    bool redo = false;  // this row's sample is on the redo list already
 
     for (;;) {
         {
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(512, 4) void encode4l_kernel(EncodeParams P) {  // 
                 bpv = 0;
                 fbp = kFarFlag;
                 pk_dirty = false;
+                redo = false;
             }
         }
         const bool fresh_row = need_new;
@@ -152,10 +155,7 @@ __global__ __launch_bounds__(512, 4) void encode4l_kernel(EncodeParams P) {  // 
                             scw[((uint32_t)d + l) & 15u] = __hiloint2double((int)rec.w, (int)rec.z);
                         } else {  // a token of 17..32 bytes: overflow list
                             const uint32_t slot = atomicAdd(ovf_cnt, 1u);
-                            if (slot < kOvfCap)
-                                ovf[slot] = make_uint4(lane | ((uint32_t)d << 8), 0u, rec.z, rec.w);
-                            else
-                                atomicMax(P.ovf_flag, 1ULL);
+                            if (slot < kOvfCap) ovf[slot] = make_uint4(lane | ((uint32_t)d << 8), 0u, rec.z, rec.w);
                         }
                     }
                 }
@@ -199,6 +199,10 @@ __global__ __launch_bounds__(512, 4) void encode4l_kernel(EncodeParams P) {  // 
         {
             const uint32_t cnt_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)*ovf_cnt);
             const uint32_t cnt = cnt_all < kOvfCap ? cnt_all : kOvfCap;
+            if (cnt_all > kOvfCap) {  // wave-uniform: entries were dropped, whichever row they belonged to
+                if (live && !redo && l == 0u) P.redo_list[atomicAdd(P.redo_count, 1ULL)] = s;
+                redo = true;
+            }
             for (uint32_t i = 0; i < cnt; ++i) {
                 const uint4 e = ovf[i];
                 const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)(e.x & 63u));

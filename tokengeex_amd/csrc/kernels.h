@@ -25,7 +25,8 @@ struct EncodeParams {
     uint32_t tokhash_seed;
     unsigned long long* err_sample; // min failing sample (init ~0)
     unsigned long long* queue;      // rows4: next unclaimed position of `order` (init 0)
-    unsigned long long* ovf_flag;   // encode4l_kernel: set when a wave's overflow list was full (init 0)
+    unsigned long long* redo_count; // encode4l_kernel: samples whose wave ran out of overflow entries (init 0) ...
+    uint32_t* redo_list;            // ... and their indices, u32[S]: encode2_kernel redoes exactly those
     double dropout;
     uint64_t seed;
     uint32_t flags;                 // timing experiments only (TGX_FLAGS env): see kernels.hip
@@ -130,7 +131,7 @@ hipError_t encode4_waves_per_simd(bool dropout, int ppl, bool root, int* out);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream);
 uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
-hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, hipStream_t stream);   // encode2.hip
+hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip
 hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream);
 hipError_t launch_encode4l(const EncodeParams& p, uint32_t num_cus, hipStream_t stream);  // encode4l.hip
 hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);

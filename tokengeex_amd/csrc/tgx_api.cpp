@@ -129,6 +129,7 @@ struct tgx_model {
     bool rev_host_built = false;    // flat_rev was built at creation (TGX_MODEL_FOR_ESTEP)
     void* d_trie_w = nullptr;       // forward / reversed tables with w = exp(score) in place of the score
     void* d_trie_rev_w = nullptr;   //   (linear-domain E-step, estep4l.hip)
+    uint64_t last_redo_samples = 0;    // samples the last encode4l pass left to encode2_kernel
     int last_encode_waves_per_cu = 0;  // resident waves per CU of the last rows4 encode launch (self-check)
     bool estep_linear_ok = false;   // tables for the linear-domain E-step kernels exist
     tgx::TokHashTable tokhash;      // token bytes -> id (rows4 trace); ok == false: not usable
@@ -382,35 +383,41 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
     } else if (use2) {
         // Tokens of 17..32 bytes: the 16-lane rows with an overflow list for the long matches (encode4l.hip);
-        // if some wave's list filled up, or with TGX_PATH=rows2, two samples per wave on 32-lane rows.
+        // samples whose wave ran out of overflow entries are redone two per wave on 32-lane rows (encode2.hip),
+        // as is the whole batch with TGX_PATH=rows2.
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
-        bool rows2 = force && strcmp(force, "rows2") == 0;
+        const bool rows2 = force && strcmp(force, "rows2") == 0;
+        m->last_redo_samples = 0;
         if (!rows2) {
-            p.ovf_flag = m->d_ctrl + 6;
+            p.redo_count = m->d_ctrl + 6;
+            p.redo_list = c->d_counts;  // free until the trace writes the token counts
             HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
             time_begin(m, "encode4l_kernel");
             HIP_TRY(tgx::launch_encode4l(p, (uint32_t)m->num_cus, m->stream));
             time_end(m);
-            unsigned long long flag = 0;
-            HIP_TRY(hipMemcpyAsync(&flag, m->d_ctrl + 6, 8, hipMemcpyDeviceToHost, m->stream));
+            unsigned long long n_redo = 0;
+            HIP_TRY(hipMemcpyAsync(&n_redo, m->d_ctrl + 6, 8, hipMemcpyDeviceToHost, m->stream));
             HIP_TRY(hipStreamSynchronize(m->stream));
-            rows2 = flag != 0;
-            if (!rows2) {
-                time_begin(m, "trace32_kernel");
-                HIP_TRY(tgx::launch_trace32(p, blocks_t, true, m->stream));
+            if (n_redo > c->n_samples) return fail(TGX_ERR_DEVICE, "redo list longer than the batch");
+            m->last_redo_samples = n_redo;
+            if (n_redo) {
+                tgx::EncodeParams q = p;
+                q.order = c->d_counts;
+                q.n_samples = n_redo;
+                HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
+                time_begin(m, "encode2_kernel");
+                HIP_TRY(tgx::launch_encode2(q, (uint32_t)m->num_cus, true, m->stream));
                 time_end(m);
             }
-        }
-        if (rows2) {
-            HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
+        } else {
             time_begin(m, "encode2_kernel");
-            HIP_TRY(tgx::launch_encode2(p, (uint32_t)m->num_cus, m->stream));
-            time_end(m);
-            time_begin(m, "trace32_kernel");
-            HIP_TRY(tgx::launch_trace32(p, blocks_t, false, m->stream));
+            HIP_TRY(tgx::launch_encode2(p, (uint32_t)m->num_cus, false, m->stream));
             time_end(m);
         }
+        time_begin(m, "trace32_kernel");
+        HIP_TRY(tgx::launch_trace32(p, blocks_t, !rows2, m->stream));
+        time_end(m);
     } else {
         time_begin(m, "encode_kernel");
         HIP_TRY(tgx::launch_encode(p, grid_blocks(m, c->n_samples), m->stream));
@@ -1377,5 +1384,6 @@ int tgx_last_kernel_times(const tgx_model* m, const char** names, float* ms, int
 
 uint32_t tgx_last_encode_waves_per_cu(const tgx_model* m) { return m ? (uint32_t)m->last_encode_waves_per_cu : 0u; }
 uint64_t tgx_last_algorithmic_bytes(const tgx_model* m) { return m ? m->last_alg_bytes : 0; }
+uint64_t tgx_last_encode_redo_samples(const tgx_model* m) { return m ? m->last_redo_samples : 0; }
 
 }  // extern "C"
