@@ -286,3 +286,44 @@ def test_long_token_overflow_redoes_only_the_samples_concerned():
     f2, o2 = tgx.pack(plain)
     assert_same_encoding(nat, ora, f2, o2)
     assert nat.last_encode_redo_samples() == 0 and "encode2_kernel" not in nat.last_kernel_times()
+
+
+def test_concurrent_calls_on_one_handle():
+    """The reference's Tokenizer is Sync: rayon workers call `&self` methods concurrently (tokenizer.rs:107-110).
+    A model handle serialises its passes internally; four host threads running different passes over different
+    batches on ONE handle get the results of the serial calls."""
+    import threading
+    flat, offs, toks, scores = corpus_and_vocab(n_bytes=3 << 20, vocab_size=3000, max_len=8192)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    cuts = [0, offs.size // 4, offs.size // 2, 3 * offs.size // 4, offs.size - 1]
+    parts = [(flat[int(offs[a]):int(offs[b])], (offs[a:b + 1] - offs[a]).astype(np.uint64))
+             for a, b in zip(cuts[:-1], cuts[1:])]
+    want = [ora.encode_batch_flat(f, o, threads=8) for f, o in parts]
+    want_freq = [ora.count_tokens_flat(f, o, threads=8) for f, o in parts]
+    got, errors = [None] * 4, []
+
+    def work(i):
+        try:
+            out = []
+            for _ in range(3):
+                res = nat.encode_batch_flat(*parts[i])
+                out.append((res.ids().copy(), res.offsets().copy()))
+                res.free()
+                corpus = tgx.NativeCorpus(*parts[i])
+                out.append(nat.count_tokens(corpus))
+                corpus.free()
+            got[i] = out
+        except Exception as e:  # surfaced below, in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(4):
+        for k in range(0, 6, 2):
+            np.testing.assert_array_equal(got[i][k][0], want[i][0])
+            np.testing.assert_array_equal(got[i][k][1], want[i][1])
+            np.testing.assert_array_equal(got[i][k + 1], want_freq[i])

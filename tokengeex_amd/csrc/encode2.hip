@@ -261,6 +261,10 @@ __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
         };
         uint32_t h_cur = 0, t_cur = 0;
         if (q >= 0) window_loads((uint32_t)q & ~63u, h_cur, t_cur);
+        // ids of a window are stored after the NEXT window's hop chain (see trace_kernel)
+        uint32_t pend_id = 0;
+        uint64_t pend_at = 0;
+        bool pend = false;
         while (q >= 0) {
             const uint32_t wq = (uint32_t)q & ~63u;
             const uint32_t idx = wq + lane;
@@ -268,14 +272,16 @@ __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
             if (lane < 40u) stage[lane] = (lane <= 24u) ? t_cur : 0u;
             uint64_t ends = 0;
             int32_t qq = (int32_t)((uint32_t)q - wq);
+            const uint32_t prev = lane - ((h & 31u) + 1u);  // where this position's token starts, relative to the window
             while (qq >= 0) {  // model.rs:113-126, 64 positions per load
-                const uint32_t hh = readlane_u32(h, (uint32_t)qq);
-                ends |= 1ULL << qq;
-                qq -= (int32_t)(hh & 31u) + 1;
+                asm("s_bitset1_b64 %0, %1" : "+s"(ends) : "s"(qq));  // ends |= 1 << qq
+                qq = (int32_t)readlane_u32(prev, (uint32_t)qq);
             }
             q = (int64_t)wq + qq;
             const uint32_t cnt = (uint32_t)__popcll(ends);
             __builtin_amdgcn_wave_barrier();
+            if (pend) P.tmp[pend_at] = pend_id;
+            pend = false;
             uint32_t h_next = 0, t_next = 0;
             if (wq >= 64u) window_loads(wq - 64u, h_next, t_next);
             if ((ends >> lane) & 1ULL) {
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
                 uint32_t id = 0;
                 bool found = false;
                 for (uint32_t probe = 0; probe <= P.tokhash_mask && !found; ++probe) {
-                    const uint4 e = table[slot];
+                    const uint4 e = load_rec(table, slot);  // one 16-byte load, not two dependent ones
                     if (e.w == 0u) break;  // empty slot: the back-pointer does not name a vocabulary token
                     if (e.x == (uint32_t)hk && e.y == (uint32_t)(hk >> 32)) {
                         id = e.z;
@@ -312,7 +318,9 @@ __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
                 // cannot happen unless a kernel bug corrupted a back-pointer: report, do not fault
                 if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
                 const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
-                P.tmp[cursor - 1 - above] = id;
+                pend_id = id;
+                pend_at = cursor - 1 - above;
+                pend = true;
             }
             cursor -= cnt;
             total += cnt;
@@ -320,6 +328,7 @@ __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
             t_cur = t_next;
             __builtin_amdgcn_wave_barrier();
         }
+        if (pend) P.tmp[pend_at] = pend_id;
         if (lane == 0) {
             P.counts[s] = total;
             if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);

@@ -621,6 +621,14 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode4_kernel(Encod
 
 // Back-trace + id emission for the rows4 path: one wave per sample, 1-byte back-pointers
 // (token length - 1), ids recovered from the token's bytes through the hash table.
+//
+// The kernel is bound by instruction issue, not by memory: a window of 64 positions holds ~14 tokens, so a
+// lookup (token bytes, hash, table probe, store: ~100 instructions) executed per window would run with a
+// quarter of its lanes.  The hop chain therefore only appends (end position, length) of the tokens it finds to
+// a per-wave ring in LDS, and the lookups run once 64 tokens are waiting: all lanes busy, one pass per ~4.6
+// windows; the token's bytes come straight from the text with one unaligned 16-byte load.
+constexpr uint32_t kTraceRing = 128;  // entries per wave: < 64 waiting + up to 64 from one window
+
 template <bool STAMP>
 __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -628,8 +636,8 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
     const uint32_t n_waves = gridDim.x * wpb;
     const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
     const uint4* __restrict__ table = reinterpret_cast<const uint4*>(P.tokhash);
-    __shared__ uint32_t stage_all[4][32];  // per wave: 80 text bytes + alignment slack + 5-dword over-read
-    uint32_t* stage = stage_all[threadIdx.x >> 6];
+    __shared__ uint2 ring_all[4][kTraceRing];
+    uint2* ring = ring_all[threadIdx.x >> 6];
     uint64_t seg[6] = {0, 0, 0, 0, 0, 0};
     uint64_t t_last = STAMP ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
     uint32_t iters = 0;
@@ -644,19 +652,54 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
         const uint8_t* __restrict__ bp = P.bp8 + bp8_base(beg, s);  // permuted inside groups of 64: bp8_perm
         const uint8_t* __restrict__ text = P.text + beg;
         uint32_t total = 0;
-        uint64_t cursor = beg + n;  // one past this sample's slice of tmp
+        uint32_t head = 0, fill = 0;  // ring: `fill` tokens wait from entry `head` on
+        uint64_t out_top = beg + n;   // one past the tmp slot of the next token looked up (ids are right-aligned)
         int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // Error::NoPath(n, n) otherwise (model.rs:119)
         if (P.flags & 4u) q = -1;
-        // Windows are visited top-down and a token is at most 16 bytes, so the next window is
-        // always the one below: its back-pointers and its text span (text[wq-16 .. wq+64), as
-        // aligned dwords, one per lane) are requested one window ahead — both come from HBM.
-        uint32_t h_cur = 0, t_cur = 0;
+
+        // ids of the first m waiting tokens: lane i takes the i-th (model.rs:113-126 emits them in this order)
+        auto lookup = [&](uint32_t m) {
+            if (lane < m && !(P.flags & 16u)) {  // flags 16: timing experiment, no lookups
+                const uint2 e = ring[(head + lane) & (kTraceRing - 1u)];
+                const uint32_t len = e.y;
+                // token = text[e.x - len .. e.x): 16 bytes from its start (the text is padded), cut to len
+                struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t w[4]; };
+                const Bytes16 raw = *reinterpret_cast<const Bytes16*>(text + (e.x - len));
+                uint32_t b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t nb = len > 4u * j ? len - 4u * j : 0u;  // bytes of the token in this dword
+                    b[j] = nb >= 4u ? raw.w[j] : (raw.w[j] & ((1u << (8u * nb)) - 1u));
+                }
+                const uint64_t hk = tok_hash64_dev(b[0], b[1], b[2], b[3], len, P.tokhash_seed);
+                uint32_t slot = (uint32_t)hk & P.tokhash_mask;
+                uint32_t id = 0;
+                bool found = false;
+                for (uint32_t probe = 0; probe <= P.tokhash_mask && !found; ++probe) {
+                    const uint4 t = load_rec(table, slot);  // one 16-byte load, not two dependent ones
+                    if (t.w == 0u) break;  // empty slot: the back-pointer does not name a vocabulary token
+                    if (t.x == (uint32_t)hk && t.y == (uint32_t)(hk >> 32)) {
+                        id = t.z;
+                        found = true;
+                    }
+                    slot = (slot + 1u) & P.tokhash_mask;
+                }
+                // cannot happen unless a kernel bug corrupted a back-pointer: report, do not fault
+                if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
+                P.tmp[out_top - 1 - lane] = id;
+            }
+            out_top -= m;
+            head = (head + m) & (kTraceRing - 1u);
+            fill -= m;
+        };
+
+        // Windows are visited top-down and a token is at most 16 bytes, so the next window is always the
+        // one below: its back-pointers are requested right after the wait for the current window's and have
+        // the whole hop chain to arrive (the compiler waits for every outstanding load at once).
+        uint32_t h_cur = 0;
         if (q >= 0) {
             const uint32_t wq0 = (uint32_t)q & ~63u;
-            const uint32_t a0 = wq0 >= 16u ? wq0 - 16u : 0u;
-            const uint32_t* __restrict__ gw = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + a0) & ~uintptr_t(3));
             h_cur = (wq0 + lane < n) ? (uint32_t)bp[bp8_perm(wq0 + lane)] : 0u;
-            t_cur = (lane <= 20u) ? gw[lane] : 0u;
         }
         TGX_STAMP(0)  // sample setup
         while (q >= 0) {
@@ -664,75 +707,35 @@ __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
             const uint32_t wq = (uint32_t)q & ~63u;
             const uint32_t idx = wq + lane;
             const uint32_t h = h_cur;
-            if (lane < 32u) stage[lane] = t_cur;  // lanes 21..31 write zeros
+            // Every lane holds where ITS position's token starts (relative to the window), so a hop is one
+            // v_readlane.  (Tried without gain: the 64 back-pointers packed into four 64-bit scalars for a
+            // pure-SALU chain; four hops per taken branch.)
+            uint32_t prev = lane - ((h & 15u) + 1u);
+            asm volatile("" : "+v"(prev) : : "memory");  // the wait for h_cur lands above the next request
+            uint32_t h_next = 0;
+            if (wq >= 64u) h_next = (uint32_t)bp[bp8_perm(wq - 64u + lane)];
             TGX_STAMP(1)  // window loads issued / consumed
             uint64_t ends = 0;
             int32_t qq = (int32_t)((uint32_t)q - wq);
-            // (Tried without gain: the 64 back-pointers packed into four 64-bit scalars for a pure-SALU hop
-            // chain, 6.4 ms against 5.9 ms per GiB; issuing this window's table probes before the NEXT
-            // window's hop chain — software pipelining — 6.5 ms.)
             while (qq >= 0) {  // model.rs:113-126, 64 positions per load
-                const uint32_t hh = readlane_u32(h, (uint32_t)qq);
-                ends |= 1ULL << qq;
-                qq -= (int32_t)(hh & 15u) + 1;
+                asm("s_bitset1_b64 %0, %1" : "+s"(ends) : "s"(qq));  // ends |= 1 << qq
+                qq = (int32_t)readlane_u32(prev, (uint32_t)qq);
             }
             q = (int64_t)wq + qq;
             const uint32_t cnt = (uint32_t)__popcll(ends);
-            __builtin_amdgcn_wave_barrier();
             TGX_STAMP(2)  // hops
-            // next window's loads: issued here (after this window's back-pointers were consumed,
-            // vector loads return in order) so that they fly during the token phase
-            uint32_t h_next = 0, t_next = 0;
-            if (wq >= 64u) {
-                const uint32_t wn = wq - 64u;
-                const uint32_t an = wn >= 16u ? wn - 16u : 0u;
-                const uint32_t* __restrict__ gwn = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + an) & ~uintptr_t(3));
-                h_next = (uint32_t)bp[bp8_perm(wn + lane)];
-                t_next = (lane <= 20u) ? gwn[lane] : 0u;
+            if ((ends >> lane) & 1ULL) {
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends, 0u));
+                ring[(head + fill + (cnt - 1u - below)) & (kTraceRing - 1u)] = make_uint2(idx + 1u, (h & 15u) + 1u);
             }
-            if (((ends >> lane) & 1ULL) && !(P.flags & 16u)) {  // flags 16: timing experiment, no token phase
-                // token = text[e - len .. e), e = idx + 1
-                const uint32_t len = (h & 15u) + 1u;
-                const uint32_t a0 = wq >= 16u ? wq - 16u : 0u;
-                const uintptr_t gaddr = reinterpret_cast<uintptr_t>(text + a0);
-                const uint32_t boff = (uint32_t)(gaddr & 3u) + (idx + 1u - len - a0);  // byte offset in stage[]
-                const uint32_t sh = boff & 3u;
-                const uint32_t* wp = stage + (boff >> 2);
-                uint32_t w[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) w[j] = wp[j];
-                uint32_t b[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
-                    const uint32_t nb = len > 4u * j ? len - 4u * j : 0u;  // bytes of the token in this dword
-                    b[j] = nb >= 4u ? v : (v & ((1u << (8u * nb)) - 1u));
-                }
-                const uint64_t hk = tok_hash64_dev(b[0], b[1], b[2], b[3], len, P.tokhash_seed);
-                uint32_t slot = (uint32_t)hk & P.tokhash_mask;
-                uint32_t id = 0;
-                bool found = false;
-                for (uint32_t probe = 0; probe <= P.tokhash_mask && !found; ++probe) {
-                    const uint4 e = table[slot];
-                    if (e.w == 0u) break;  // empty slot: the back-pointer does not name a vocabulary token
-                    if (e.x == (uint32_t)hk && e.y == (uint32_t)(hk >> 32)) {
-                        id = e.z;
-                        found = true;
-                    }
-                    slot = (slot + 1u) & P.tokhash_mask;
-                }
-                // cannot happen unless a kernel bug corrupted a back-pointer: report, do not fault
-                if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
-                const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
-                P.tmp[cursor - 1 - above] = id;
-            }
-            TGX_STAMP(3)  // token bytes, hash, table probe, id store
-            cursor -= cnt;
+            fill += cnt;
             total += cnt;
-            h_cur = h_next;
-            t_cur = t_next;
             __builtin_amdgcn_wave_barrier();
+            if (fill >= 64u) lookup(64u);
+            TGX_STAMP(3)  // ring append, lookups
+            h_cur = h_next;
         }
+        if (fill) lookup(fill);
         if (lane == 0) {
             P.counts[s] = total;
             if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);

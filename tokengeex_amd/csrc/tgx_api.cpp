@@ -338,6 +338,21 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         time_begin(m, "encode4_kernel");
         HIP_TRY(tgx::launch_encode4(p, ppl, waves, blocks4, root, m->stream));
+        if (p.flags & 64u) {
+            // experiment (TGX_DEBUG=1 TGX_FLAGS=64): trace_kernel over the PREVIOUS pass's back-pointers (same
+            // corpus: same bytes) on a second stream while encode4_kernel runs; the timed pair covers both
+            static hipStream_t s2 = nullptr;
+            static hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (!s2) {
+                HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
+            }
+            const uint32_t bt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
+            HIP_TRY(tgx::launch_trace(p, bt, s2));
+            HIP_TRY(hipEventRecord(ev1, s2));
+            HIP_TRY(hipStreamWaitEvent(m->stream, ev1, 0));
+        }
         time_end(m);
         if (d_stamps) {  // diagnostic: mean cycles per iteration and phase over all waves
             std::vector<unsigned long long> h(n_stamp_waves * 8);
