@@ -157,4 +157,36 @@ __device__ __forceinline__ uint64_t tok_hash64_dev(uint32_t w0, uint32_t w1, uin
 }
 
 
+// same function as tgx::tok_hash64_long (trie_build.h): tok_hash64 continued over four more dwords
+__device__ __forceinline__ uint64_t tok_hash64_long_dev(const uint32_t* w, uint32_t len, uint32_t seed) {
+    uint32_t a = (w[0] ^ (len << 27) ^ seed) * 0x85EBCA6Bu;
+    a ^= a >> 15;
+    uint32_t b = a;
+    a = (a + w[1]) * 0xC2B2AE35u;
+    a ^= a >> 13;
+    b = rotl32_dev(b, 11) ^ a;
+    a = (a + w[2]) * 0x27D4EB2Fu;
+    a ^= a >> 16;
+    b = rotl32_dev(b, 11) ^ a;
+    a = (a + w[3]) * 0x165667B1u;
+    a ^= a >> 15;
+    b = rotl32_dev(b, 11) + (w[0] ^ rotl32_dev(w[1], 8) ^ rotl32_dev(w[2], 16) ^ rotl32_dev(w[3], 24));
+    if (len > 16u) {
+        a = (a + w[4]) * 0x85EBCA6Bu;
+        a ^= a >> 15;
+        b = rotl32_dev(b, 11) ^ a;
+        a = (a + w[5]) * 0xC2B2AE35u;
+        a ^= a >> 13;
+        b = rotl32_dev(b, 11) ^ a;
+        a = (a + w[6]) * 0x27D4EB2Fu;
+        a ^= a >> 16;
+        b = rotl32_dev(b, 11) ^ a;
+        a = (a + w[7]) * 0x165667B1u;
+        a ^= a >> 15;
+        b = rotl32_dev(b, 11) + (w[4] ^ rotl32_dev(w[5], 8) ^ rotl32_dev(w[6], 16) ^ rotl32_dev(w[7], 24));
+    }
+    return ((uint64_t)b << 32) | a;
+}
+
+
 }  // namespace tgx

@@ -15,6 +15,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "trace_body.h"
 
 namespace tgx {
 
@@ -198,142 +199,12 @@ __global__ __launch_bounds__(640) void encode2_kernel(EncodeParams P) {
     }
 }
 
-// same function as tgx::tok_hash64_long (trie_build.h): tok_hash64 continued over four more dwords
-__device__ __forceinline__ uint64_t tok_hash64_long_dev(const uint32_t* w, uint32_t len, uint32_t seed) {
-    uint32_t a = (w[0] ^ (len << 27) ^ seed) * 0x85EBCA6Bu;
-    a ^= a >> 15;
-    uint32_t b = a;
-    a = (a + w[1]) * 0xC2B2AE35u;
-    a ^= a >> 13;
-    b = rotl32_dev(b, 11) ^ a;
-    a = (a + w[2]) * 0x27D4EB2Fu;
-    a ^= a >> 16;
-    b = rotl32_dev(b, 11) ^ a;
-    a = (a + w[3]) * 0x165667B1u;
-    a ^= a >> 15;
-    b = rotl32_dev(b, 11) + (w[0] ^ rotl32_dev(w[1], 8) ^ rotl32_dev(w[2], 16) ^ rotl32_dev(w[3], 24));
-    if (len > 16u) {
-        a = (a + w[4]) * 0x85EBCA6Bu;
-        a ^= a >> 15;
-        b = rotl32_dev(b, 11) ^ a;
-        a = (a + w[5]) * 0xC2B2AE35u;
-        a ^= a >> 13;
-        b = rotl32_dev(b, 11) ^ a;
-        a = (a + w[6]) * 0x27D4EB2Fu;
-        a ^= a >> 16;
-        b = rotl32_dev(b, 11) ^ a;
-        a = (a + w[7]) * 0x165667B1u;
-        a ^= a >> 15;
-        b = rotl32_dev(b, 11) + (w[4] ^ rotl32_dev(w[5], 8) ^ rotl32_dev(w[6], 16) ^ rotl32_dev(w[7], 24));
-    }
-    return ((uint64_t)b << 32) | a;
-}
-
-// trace_kernel (kernels.hip) for tokens of up to 32 bytes: one wave per sample, plain 1-byte back-pointers
-// (token length - 1, 0..31), ids recovered from the token's bytes through the hash table.
+// trace_kernel (kernels.hip) for tokens of up to 32 bytes (trace_body.h).
 // PERM: the back-pointer bytes are in encode4_kernel's permuted layout (bp8_perm; encode4l_kernel), else plain
 template <bool PERM>
 __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wpb = blockDim.x >> 6;
-    const uint32_t n_waves = gridDim.x * wpb;
-    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-    const uint4* __restrict__ table = reinterpret_cast<const uint4*>(P.tokhash);
-    __shared__ uint32_t stage_all[4][40];  // per wave: 96 text bytes + alignment slack + 9-dword over-read
-    uint32_t* stage = stage_all[threadIdx.x >> 6];
-    for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
-        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
-        const uint64_t beg = first_u64(P.offs[s]);
-        const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
-        const uint32_t reach_n = (n == 0) ? 1u : (uint32_t)__builtin_amdgcn_readfirstlane((int)P.status[s]);
-        const uint8_t* __restrict__ bp = P.bp8 + bp8_base(beg, s);
-        const uint8_t* __restrict__ text = P.text + beg;
-        uint32_t total = 0;
-        uint64_t cursor = beg + n;  // one past this sample's slice of tmp
-        int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // Error::NoPath(n, n) otherwise (model.rs:119)
-        // windows of 64 positions, top-down; a token is at most 32 bytes, so the next window is always the
-        // one below: its back-pointers and text span (text[wq-32 .. wq+64)) are requested one window ahead
-        auto window_loads = [&](uint32_t wq, uint32_t& hraw, uint32_t& traw) {
-            const uint32_t a0 = wq >= 32u ? wq - 32u : 0u;
-            const uint32_t* __restrict__ gw = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(text + a0) & ~uintptr_t(3));
-            hraw = (wq + lane < n) ? (uint32_t)bp[PERM ? bp8_perm(wq + lane) : wq + lane] : 0u;
-            traw = (lane <= 24u) ? gw[lane] : 0u;
-        };
-        uint32_t h_cur = 0, t_cur = 0;
-        if (q >= 0) window_loads((uint32_t)q & ~63u, h_cur, t_cur);
-        // ids of a window are stored after the NEXT window's hop chain (see trace_kernel)
-        uint32_t pend_id = 0;
-        uint64_t pend_at = 0;
-        bool pend = false;
-        while (q >= 0) {
-            const uint32_t wq = (uint32_t)q & ~63u;
-            const uint32_t idx = wq + lane;
-            const uint32_t h = h_cur;
-            if (lane < 40u) stage[lane] = (lane <= 24u) ? t_cur : 0u;
-            uint64_t ends = 0;
-            int32_t qq = (int32_t)((uint32_t)q - wq);
-            const uint32_t prev = lane - ((h & 31u) + 1u);  // where this position's token starts, relative to the window
-            while (qq >= 0) {  // model.rs:113-126, 64 positions per load
-                asm("s_bitset1_b64 %0, %1" : "+s"(ends) : "s"(qq));  // ends |= 1 << qq
-                qq = (int32_t)readlane_u32(prev, (uint32_t)qq);
-            }
-            q = (int64_t)wq + qq;
-            const uint32_t cnt = (uint32_t)__popcll(ends);
-            __builtin_amdgcn_wave_barrier();
-            if (pend) P.tmp[pend_at] = pend_id;
-            pend = false;
-            uint32_t h_next = 0, t_next = 0;
-            if (wq >= 64u) window_loads(wq - 64u, h_next, t_next);
-            if ((ends >> lane) & 1ULL) {
-                // token = text[e - len .. e), e = idx + 1
-                const uint32_t len = (h & 31u) + 1u;
-                const uint32_t a0 = wq >= 32u ? wq - 32u : 0u;
-                const uintptr_t gaddr = reinterpret_cast<uintptr_t>(text + a0);
-                const uint32_t boff = (uint32_t)(gaddr & 3u) + (idx + 1u - len - a0);  // byte offset in stage[]
-                const uint32_t sh = boff & 3u;
-                const uint32_t* wp = stage + (boff >> 2);
-                uint32_t w[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) w[j] = wp[j];
-                uint32_t b[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t v = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
-                    const uint32_t nb = len > 4u * j ? len - 4u * j : 0u;  // bytes of the token in this dword
-                    b[j] = nb >= 4u ? v : (v & ((1u << (8u * nb)) - 1u));
-                }
-                const uint64_t hk = tok_hash64_long_dev(b, len, P.tokhash_seed);
-                uint32_t slot = (uint32_t)hk & P.tokhash_mask;
-                uint32_t id = 0;
-                bool found = false;
-                for (uint32_t probe = 0; probe <= P.tokhash_mask && !found; ++probe) {
-                    const uint4 e = load_rec(table, slot);  // one 16-byte load, not two dependent ones
-                    if (e.w == 0u) break;  // empty slot: the back-pointer does not name a vocabulary token
-                    if (e.x == (uint32_t)hk && e.y == (uint32_t)(hk >> 32)) {
-                        id = e.z;
-                        found = true;
-                    }
-                    slot = (slot + 1u) & P.tokhash_mask;
-                }
-                // cannot happen unless a kernel bug corrupted a back-pointer: report, do not fault
-                if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
-                const uint32_t above = (uint32_t)__popcll((ends >> lane) >> 1);
-                pend_id = id;
-                pend_at = cursor - 1 - above;
-                pend = true;
-            }
-            cursor -= cnt;
-            total += cnt;
-            h_cur = h_next;
-            t_cur = t_next;
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (pend) P.tmp[pend_at] = pend_id;
-        if (lane == 0) {
-            P.counts[s] = total;
-            if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);
-        }
-    }
+    __shared__ uint2 ring_all[4][kTraceRing];
+    trace_body<32, PERM, false>(P, ring_all[threadIdx.x >> 6]);
 }
 
 // two blocks of five waves per CU: 10 x 16 KiB of LDS

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "trace_body.h"
 #include "device_common.h"
 
 namespace tgx {
@@ -619,133 +620,11 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode4_kernel(Encod
     }
 }
 
-// Back-trace + id emission for the rows4 path: one wave per sample, 1-byte back-pointers
-// (token length - 1), ids recovered from the token's bytes through the hash table.
-//
-// The kernel is bound by instruction issue, not by memory: a window of 64 positions holds ~14 tokens, so a
-// lookup (token bytes, hash, table probe, store: ~100 instructions) executed per window would run with a
-// quarter of its lanes.  The hop chain therefore only appends (end position, length) of the tokens it finds to
-// a per-wave ring in LDS, and the lookups run once 64 tokens are waiting: all lanes busy, one pass per ~4.6
-// windows; the token's bytes come straight from the text with one unaligned 16-byte load.
-constexpr uint32_t kTraceRing = 128;  // entries per wave: < 64 waiting + up to 64 from one window
-
+// Back-trace + id emission for the rows4 path (trace_body.h).
 template <bool STAMP>
 __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wpb = blockDim.x >> 6;
-    const uint32_t n_waves = gridDim.x * wpb;
-    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-    const uint4* __restrict__ table = reinterpret_cast<const uint4*>(P.tokhash);
     __shared__ uint2 ring_all[4][kTraceRing];
-    uint2* ring = ring_all[threadIdx.x >> 6];
-    uint64_t seg[6] = {0, 0, 0, 0, 0, 0};
-    uint64_t t_last = STAMP ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
-    uint32_t iters = 0;
-    // Static round-robin over the longest-first order.  (Claiming samples from a global counter, as
-    // encode4_kernel does per row, gained nothing here on 64 KiB samples and cost 2-5x on corpora of
-    // short samples: one atomic per sample on one address serialises the waves.)
-    for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
-        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
-        const uint64_t beg = first_u64(P.offs[s]);
-        const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
-        const uint32_t reach_n = (n == 0) ? 1u : (uint32_t)__builtin_amdgcn_readfirstlane((int)P.status[s]);
-        const uint8_t* __restrict__ bp = P.bp8 + bp8_base(beg, s);  // permuted inside groups of 64: bp8_perm
-        const uint8_t* __restrict__ text = P.text + beg;
-        uint32_t total = 0;
-        uint32_t head = 0, fill = 0;  // ring: `fill` tokens wait from entry `head` on
-        uint64_t out_top = beg + n;   // one past the tmp slot of the next token looked up (ids are right-aligned)
-        int64_t q = reach_n ? (int64_t)n - 1 : (int64_t)-1;  // Error::NoPath(n, n) otherwise (model.rs:119)
-        if (P.flags & 4u) q = -1;
-
-        // ids of the first m waiting tokens: lane i takes the i-th (model.rs:113-126 emits them in this order)
-        auto lookup = [&](uint32_t m) {
-            if (lane < m && !(P.flags & 16u)) {  // flags 16: timing experiment, no lookups
-                const uint2 e = ring[(head + lane) & (kTraceRing - 1u)];
-                const uint32_t len = e.y;
-                // token = text[e.x - len .. e.x): 16 bytes from its start (the text is padded), cut to len
-                struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t w[4]; };
-                const Bytes16 raw = *reinterpret_cast<const Bytes16*>(text + (e.x - len));
-                uint32_t b[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t nb = len > 4u * j ? len - 4u * j : 0u;  // bytes of the token in this dword
-                    b[j] = nb >= 4u ? raw.w[j] : (raw.w[j] & ((1u << (8u * nb)) - 1u));
-                }
-                const uint64_t hk = tok_hash64_dev(b[0], b[1], b[2], b[3], len, P.tokhash_seed);
-                uint32_t slot = (uint32_t)hk & P.tokhash_mask;
-                uint32_t id = 0;
-                bool found = false;
-                for (uint32_t probe = 0; probe <= P.tokhash_mask && !found; ++probe) {
-                    const uint4 t = load_rec(table, slot);  // one 16-byte load, not two dependent ones
-                    if (t.w == 0u) break;  // empty slot: the back-pointer does not name a vocabulary token
-                    if (t.x == (uint32_t)hk && t.y == (uint32_t)(hk >> 32)) {
-                        id = t.z;
-                        found = true;
-                    }
-                    slot = (slot + 1u) & P.tokhash_mask;
-                }
-                // cannot happen unless a kernel bug corrupted a back-pointer: report, do not fault
-                if (!found) atomicMin(P.err_sample, (unsigned long long)s | (1ULL << 62));
-                P.tmp[out_top - 1 - lane] = id;
-            }
-            out_top -= m;
-            head = (head + m) & (kTraceRing - 1u);
-            fill -= m;
-        };
-
-        // Windows are visited top-down and a token is at most 16 bytes, so the next window is always the
-        // one below: its back-pointers are requested right after the wait for the current window's and have
-        // the whole hop chain to arrive (the compiler waits for every outstanding load at once).
-        uint32_t h_cur = 0;
-        if (q >= 0) {
-            const uint32_t wq0 = (uint32_t)q & ~63u;
-            h_cur = (wq0 + lane < n) ? (uint32_t)bp[bp8_perm(wq0 + lane)] : 0u;
-        }
-        TGX_STAMP(0)  // sample setup
-        while (q >= 0) {
-            iters++;
-            const uint32_t wq = (uint32_t)q & ~63u;
-            const uint32_t idx = wq + lane;
-            const uint32_t h = h_cur;
-            // Every lane holds where ITS position's token starts (relative to the window), so a hop is one
-            // v_readlane.  (Tried without gain: the 64 back-pointers packed into four 64-bit scalars for a
-            // pure-SALU chain; four hops per taken branch.)
-            uint32_t prev = lane - ((h & 15u) + 1u);
-            asm volatile("" : "+v"(prev) : : "memory");  // the wait for h_cur lands above the next request
-            uint32_t h_next = 0;
-            if (wq >= 64u) h_next = (uint32_t)bp[bp8_perm(wq - 64u + lane)];
-            TGX_STAMP(1)  // window loads issued / consumed
-            uint64_t ends = 0;
-            int32_t qq = (int32_t)((uint32_t)q - wq);
-            while (qq >= 0) {  // model.rs:113-126, 64 positions per load
-                asm("s_bitset1_b64 %0, %1" : "+s"(ends) : "s"(qq));  // ends |= 1 << qq
-                qq = (int32_t)readlane_u32(prev, (uint32_t)qq);
-            }
-            q = (int64_t)wq + qq;
-            const uint32_t cnt = (uint32_t)__popcll(ends);
-            TGX_STAMP(2)  // hops
-            if ((ends >> lane) & 1ULL) {
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(ends >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ends, 0u));
-                ring[(head + fill + (cnt - 1u - below)) & (kTraceRing - 1u)] = make_uint2(idx + 1u, (h & 15u) + 1u);
-            }
-            fill += cnt;
-            total += cnt;
-            __builtin_amdgcn_wave_barrier();
-            if (fill >= 64u) lookup(64u);
-            TGX_STAMP(3)  // ring append, lookups
-            h_cur = h_next;
-        }
-        if (fill) lookup(fill);
-        if (lane == 0) {
-            P.counts[s] = total;
-            if (!reach_n) atomicMin(P.err_sample, (unsigned long long)s);
-        }
-    }
-    if (STAMP && lane == 0 && P.stamps) {
-        unsigned long long* o = P.stamps + (size_t)wave_id * 8u;
-        for (int i = 0; i < 5; ++i) o[i] = seg[i];
-        o[5] = iters;
-    }
+    trace_body<16, true, STAMP>(P, ring_all[threadIdx.x >> 6]);
 }
 
 // counts[S] -> offsets[S+1] (exclusive prefix sum), one workgroup.
