@@ -118,8 +118,10 @@ def main() -> None:
         # correction); counters cannot be read from inside this process, so the committed figure of the
         # last profiled run is reported, and only for the workload it was taken on
         traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "h_final_pmc_traffic.json")
-        if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length) == (1024, 32000, "mixed", 16):
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01")
+        tpath = next((t for t in (os.path.join(pdir, n) for n in ("m_final_pmc_traffic.json", "h_final_pmc_traffic.json"))
+                      if os.path.exists(t)), "")
+        if tpath and (args.size_mb, args.vocab, args.kind, args.max_token_length) == (1024, 32000, "mixed", 16):
             with open(tpath) as f:
                 traffic = json.load(f).get(dom.split("<")[0], {}).get("hbm_bytes_per_launch_corrected")
         out = {

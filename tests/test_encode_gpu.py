@@ -327,3 +327,23 @@ def test_concurrent_calls_on_one_handle():
             np.testing.assert_array_equal(got[i][k][0], want[i][0])
             np.testing.assert_array_equal(got[i][k][1], want[i][1])
             np.testing.assert_array_equal(got[i][k + 1], want_freq[i])
+
+
+@pytest.mark.parametrize("max_len", [16, 24])
+def test_trace_ring_extremes(max_len):
+    """The trace looks tokens up 64 at a time from a ring of 128 entries per wave (trace_body.h).  Dropout 1.0
+    makes every token one byte (KAT 2, src/model.rs:217-236): 64 tokens per window, the ring wraps on every
+    window; a vocabulary whose multi-byte tokens are all long gives a few tokens per window and partial last
+    batches.  Sample lengths around the multiples of 64."""
+    rng = np.random.default_rng(3)
+    toks = [bytes([c]) for c in range(256)] + [bytes(rng.integers(97, 101, size=max_len - int(rng.integers(0, 3)), dtype=np.uint8))
+                                               for _ in range(300)]
+    toks = list(dict.fromkeys(toks))
+    scores = np.concatenate([np.full(256, -8.0), -1.0 - rng.random(len(toks) - 256)])
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    texts = [bytes(rng.integers(97, 101, size=n, dtype=np.uint8)) for n in (1, 63, 64, 65, 127, 128, 129, 191, 192, 4095, 4096, 4097, 20000)]
+    texts += [b"".join(toks[256 + int(i)] for i in rng.integers(0, len(toks) - 256, size=400)) for _ in range(4)]
+    flat, offs = tgx.pack(texts)
+    assert_same_encoding(nat, ora, flat, offs)
+    ids, _ = assert_same_encoding(nat, ora, flat, offs, dropout=1.0, seed=1)
+    np.testing.assert_array_equal(ids, flat.astype(np.uint32))   # one token per byte, id = byte value
