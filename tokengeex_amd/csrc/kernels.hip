@@ -633,12 +633,19 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __res
                                                            uint64_t n) {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
+    constexpr uint32_t E = 8;  // consecutive counts per thread and round: 8192 per round
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint64_t base = 0; base < n; base += 1024) {
-        const uint64_t i = base + tid;
-        uint64_t v = (i < n) ? counts[i] : 0;
+    for (uint64_t base = 0; base < n; base += 1024u * E) {
+        const uint64_t i0 = base + (uint64_t)tid * E;
+        uint32_t c[E];
+        uint64_t v = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < E; ++e) {
+            c[e] = (i0 + e < n) ? counts[i0 + e] : 0u;
+            v += c[e];
+        }
         uint64_t x = v;
         for (int off = 1; off < 64; off <<= 1) {
             uint64_t y = __shfl_up(x, off);
@@ -649,9 +656,14 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __res
         uint64_t wprefix = 0;
         for (uint32_t w = 0; w < wave; ++w) wprefix += wsum[w];
         const uint64_t carry = carry_s;
-        if (i < n) offsets[i] = carry + wprefix + x - v;
+        uint64_t run = carry + wprefix + x - v;
+#pragma unroll
+        for (uint32_t e = 0; e < E; ++e) {
+            if (i0 + e < n) offsets[i0 + e] = run;
+            run += c[e];
+        }
         __syncthreads();
-        if (tid == 1023) carry_s = carry + wprefix + x;
+        if (tid == 1023) carry_s = run;
         __syncthreads();
     }
     if (tid == 0) offsets[n] = carry_s;
@@ -669,7 +681,12 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams P) {
         const uint32_t cnt = (uint32_t)(P.out_offs[s + 1] - o0);
         const uint32_t* __restrict__ src = P.tmp + (end - cnt);
         uint32_t* __restrict__ dst = P.ids + o0;
-        for (uint32_t i = lane; i < cnt; i += 64) dst[i] = src[i];
+        // 16 bytes per lane (neither side is 16-byte aligned: unaligned dwordx4), the last 0..3 ids one by one
+        struct __attribute__((packed, aligned(4))) Ids4 { uint32_t w[4]; };
+        const uint32_t body = cnt & ~3u;
+        for (uint32_t i = lane * 4u; i < body; i += 256u)
+            *reinterpret_cast<Ids4*>(dst + i) = *reinterpret_cast<const Ids4*>(src + i);
+        if (body + lane < cnt) dst[body + lane] = src[body + lane];
     }
 }
 
