@@ -65,7 +65,14 @@ __global__ __launch_bounds__(512, 4) void encode4l_kernel(EncodeParams P) {  // 
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie);
-    unsigned char* wbase = smem + (size_t)wave * kL4WaveBytes;
+    // the 256 records of the root's children in LDS: the first step of every walk reads them there (as encode4_kernel)
+    const uint4* rootc = reinterpret_cast<const uint4*>(smem);
+    {
+        uint4* rw = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(P.root_base & ~255u) + i];
+        __syncthreads();
+    }
+    unsigned char* wbase = smem + 4096u + (size_t)wave * kL4WaveBytes;
     double* sc = reinterpret_cast<double*>(wbase);
     uint32_t* ovf_cnt = reinterpret_cast<uint32_t*>(wbase + kL4GroupBytes);
     uint4* ovf = reinterpret_cast<uint4*>(wbase + kL4GroupBytes + 16u);  // {lane | depth << 8, -, score lo, score hi}
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(512, 4) void encode4l_kernel(EncodeParams P) {  // 
             if (alive) {
                 const uint32_t c = (bytes[d >> 2] >> ((d & 3) * 8)) & 0xFFu;
                 const uint32_t t = base ^ c;
-                const uint4 rec = load_rec(trie, t);
+                const uint4 rec = d == 0 ? rootc[t & 255u] : load_rec(trie, t);
                 alive = rec.x == cur;
                 if (alive) {
                     cur = t;
@@ -268,7 +275,7 @@ hipError_t launch_encode4l(const EncodeParams& p, uint32_t num_cus, hipStream_t 
     auto fn = p.dropout > 0.0 ? encode4l_kernel<true> : encode4l_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * waves), waves * kL4WaveBytes, stream, p);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * waves), 4096u + waves * kL4WaveBytes, stream, p);
     return hipGetLastError();
 }
 
