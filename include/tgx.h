@@ -128,6 +128,11 @@ uint64_t tgx_result_num_tokens(const tgx_result *r);
 /* Host pointers (copied from the device on first use); valid until tgx_result_free. */
 const uint32_t *tgx_result_ids(tgx_result *r);
 const uint64_t *tgx_result_offsets(tgx_result *r);
+/* The same arrays copied from the device straight into caller-owned memory (a binding's Vec<u32> / numpy
+ * array: no intermediate host copy); `cap` = elements available at dst, at least num_tokens resp.
+ * num_samples + 1, else TGX_ERR_INVALID. */
+tgx_status tgx_result_copy_ids(const tgx_result *r, uint32_t *dst, uint64_t cap);
+tgx_status tgx_result_copy_offsets(const tgx_result *r, uint64_t *dst, uint64_t cap);
 /* Device pointers of the same arrays (for callers that keep ids in HBM). */
 const void *tgx_result_ids_device(const tgx_result *r);
 const void *tgx_result_offsets_device(const tgx_result *r);

@@ -347,3 +347,23 @@ def test_trace_ring_extremes(max_len):
     assert_same_encoding(nat, ora, flat, offs)
     ids, _ = assert_same_encoding(nat, ora, flat, offs, dropout=1.0, seed=1)
     np.testing.assert_array_equal(ids, flat.astype(np.uint32))   # one token per byte, id = byte value
+
+
+def test_result_accessors_agree():
+    """tgx_result_ids / _offsets (library-owned host copy) and tgx_result_copy_ids / _copy_offsets (caller-owned
+    memory) return the same arrays; a destination that is too small is refused."""
+    import ctypes as C
+    from tokengeex_amd import _lib
+    flat, offs, toks, scores = corpus_and_vocab(n_bytes=1 << 20, vocab_size=2000, max_len=4096)
+    nat = tgx.NativeModel(toks, scores)
+    res = nat.encode_batch_flat(flat, offs)
+    ids, oo = res.ids(), res.offsets()
+    t, n = res.num_tokens, res.num_samples
+    p_ids = C.cast(_lib.lib.tgx_result_ids(res._h), C.POINTER(C.c_uint32))
+    p_off = C.cast(_lib.lib.tgx_result_offsets(res._h), C.POINTER(C.c_uint64))
+    np.testing.assert_array_equal(np.ctypeslib.as_array(p_ids, shape=(t,)), ids)
+    np.testing.assert_array_equal(np.ctypeslib.as_array(p_off, shape=(n + 1,)), oo)
+    assert oo[-1] == t and oo[0] == 0
+    small = np.empty(max(t - 1, 1), np.uint32)
+    assert _lib.lib.tgx_result_copy_ids(res._h, _lib.ptr(small), t - 1) == _lib.ERR_INVALID
+    res.free()

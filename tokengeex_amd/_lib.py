@@ -48,6 +48,8 @@ SYMBOLS = {
     "tgx_result_num_tokens": (_u64, [_vp]),
     "tgx_result_ids": (_vp, [_vp]),
     "tgx_result_offsets": (_vp, [_vp]),
+    "tgx_result_copy_ids": (_i, [_vp, _vp, _u64]),
+    "tgx_result_copy_offsets": (_i, [_vp, _vp, _u64]),
     "tgx_result_ids_device": (_vp, [_vp]),
     "tgx_result_offsets_device": (_vp, [_vp]),
     "tgx_result_free": (None, [_vp]),
@@ -151,20 +153,17 @@ class NativeResult:
         return lib.tgx_result_num_samples(self._h)
 
     def offsets(self) -> np.ndarray:
-        p = lib.tgx_result_offsets(self._h)
-        if not p:
-            check(ERR_DEVICE)
-        n = self.num_samples + 1
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n,)).copy()
+        out = np.empty(self.num_samples + 1, np.uint64)
+        check(lib.tgx_result_copy_offsets(self._h, ptr(out), out.size))
+        return out
 
     def ids(self) -> np.ndarray:
         t = self.num_tokens
         if t == 0:
             return np.zeros(0, np.uint32)
-        p = lib.tgx_result_ids(self._h)
-        if not p:
-            check(ERR_DEVICE)
-        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(t,)).copy()
+        out = np.empty(t, np.uint32)   # the device copy lands in the array itself
+        check(lib.tgx_result_copy_ids(self._h, ptr(out), t))
+        return out
 
     def ids_device_ptr(self) -> int:
         return lib.tgx_result_ids_device(self._h) or 0

@@ -876,6 +876,23 @@ const uint64_t* tgx_result_offsets(tgx_result* r) {
     return r->h_offs.data();
 }
 
+tgx_status tgx_result_copy_ids(const tgx_result* r, uint32_t* dst, uint64_t cap) {
+    if (!r || (!dst && r->n_tokens)) return fail(TGX_ERR_INVALID, "tgx_result_copy_ids: NULL argument");
+    if (cap < r->n_tokens) return fail(TGX_ERR_INVALID, "tgx_result_copy_ids: %llu ids, room for %llu", (unsigned long long)r->n_tokens, (unsigned long long)cap);
+    if (!r->n_tokens) return TGX_OK;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipMemcpy(dst, r->d_ids, r->n_tokens * 4, hipMemcpyDeviceToHost));
+    return TGX_OK;
+}
+
+tgx_status tgx_result_copy_offsets(const tgx_result* r, uint64_t* dst, uint64_t cap) {
+    if (!r || !dst) return fail(TGX_ERR_INVALID, "tgx_result_copy_offsets: NULL argument");
+    if (cap < r->n_samples + 1) return fail(TGX_ERR_INVALID, "tgx_result_copy_offsets: %llu offsets, room for %llu", (unsigned long long)(r->n_samples + 1), (unsigned long long)cap);
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipMemcpy(dst, r->d_offs, (r->n_samples + 1) * 8, hipMemcpyDeviceToHost));
+    return TGX_OK;
+}
+
 const void* tgx_result_ids_device(const tgx_result* r) { return r ? r->d_ids : nullptr; }
 const void* tgx_result_offsets_device(const tgx_result* r) { return r ? r->d_offs : nullptr; }
 
