@@ -367,3 +367,57 @@ def test_result_accessors_agree():
     small = np.empty(max(t - 1, 1), np.uint32)
     assert _lib.lib.tgx_result_copy_ids(res._h, _lib.ptr(small), t - 1) == _lib.ERR_INVALID
     res.free()
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] at full size (1 GiB, 32 000-entry vocabulary) through properties that need no
+    oracle pass of that size: decoding the ids gives back every byte of the text (src/model.rs:146-160, checked
+    chunk by chunk), a second pass and a pass over the two halves of the batch give the same ids (samples are
+    independent, src/tokenizer.rs:107-110), and the first 8 MiB agree with the CPU oracle bit for bit."""
+    vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
+    toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
+    flat, offs = synth.make_corpus(1024 << 20, "mixed", seed_offset=1000)
+    nat = tgx.NativeModel(toks, scores)
+    corpus = tgx.NativeCorpus(flat, offs)
+    res = nat.encode_corpus(corpus)
+    ids, oo = res.ids(), res.offsets()
+    res.free()
+    res = nat.encode_corpus(corpus)
+    np.testing.assert_array_equal(res.ids(), ids)          # deterministic
+    res.free()
+    corpus.free()
+    # token bytes as a flat table
+    tlen = np.array([len(t) for t in toks], np.int64)
+    toff = np.concatenate([[0], np.cumsum(tlen)])
+    tbytes = np.frombuffer(b"".join(toks), np.uint8)
+    o = offs.astype(np.int64)
+    t = oo.astype(np.int64)
+    assert t[-1] == ids.size and ids.max() < len(toks)
+    # per sample: the token lengths add up to the sample's length
+    lens = tlen[ids]
+    per_sample = np.add.reduceat(lens, t[:-1].clip(max=max(ids.size - 1, 0)))
+    per_sample[t[1:] == t[:-1]] = 0                         # reduceat's convention for empty slices
+    np.testing.assert_array_equal(per_sample, o[1:] - o[:-1])
+    # decode == text, in chunks of about 64 MiB of text
+    S = o.size - 1
+    a = 0
+    while a < S:
+        b = min(int(np.searchsorted(o, o[a] + (64 << 20), side="right")), S)
+        b = max(b, a + 1)
+        cid = ids[t[a]:t[b]]
+        cl = tlen[cid]
+        starts = np.cumsum(cl) - cl
+        idx = np.repeat(toff[cid] - starts, cl) + np.arange(int(cl.sum()), dtype=np.int64)
+        np.testing.assert_array_equal(tbytes[idx], flat[o[a]:o[b]])
+        a = b
+    # the two halves of the batch on their own
+    h = S // 2
+    for lo, hi in ((0, h), (h, S)):
+        sub = nat.encode_batch_flat(flat[o[lo]:o[hi]], (offs[lo:hi + 1] - offs[lo]).astype(np.uint64))
+        np.testing.assert_array_equal(sub.ids(), ids[t[lo]:t[hi]])
+        sub.free()
+    # and the oracle on the head of the corpus
+    k = int(np.searchsorted(o, 8 << 20))
+    want_ids, want_offs = orc.OracleModel(toks, scores).encode_batch_flat(flat[:o[k]], offs[:k + 1], threads=8)
+    np.testing.assert_array_equal(ids[:t[k]], want_ids)
+    np.testing.assert_array_equal(oo[:k + 1], want_offs)
