@@ -132,11 +132,19 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     // Expansion order: descending weight, the older node first among equals.  A parent weighs at least as
     // much as any of its children and was created before them, so one sort gives an order in which every
     // node comes after its parent (the order a priority queue over the frontier would pop them in).
+    // (sorted as contiguous (key, node) pairs: weights are finite and >= 0, so their bit patterns order like
+    // the values; the key is the complement for a descending order)
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        const double w = weight[i] + 0.0;  // -0.0 -> +0.0
+        uint64_t bits;
+        std::memcpy(&bits, &w, 8);
+        keyed[i] = {~bits, i};
+    }
+    std::sort(keyed.begin(), keyed.end());
     std::vector<uint32_t> expand(n_nodes);
-    for (uint32_t i = 0; i < n_nodes; i++) expand[i] = i;
-    std::sort(expand.begin(), expand.end(), [&weight](uint32_t a, uint32_t b) {
-        return weight[a] != weight[b] ? weight[a] > weight[b] : a < b;
-    });
+    for (uint32_t i = 0; i < n_nodes; i++) expand[i] = keyed[i].second;
+    keyed = std::vector<std::pair<uint64_t, uint32_t>>();
     for (uint32_t node : expand) {
         uint32_t lo = row[node], hi = row[node + 1], k = hi - lo;
         if (k == 0) continue;
@@ -155,21 +163,28 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
             for (uint32_t b = ba.headk; b < ba.n_blocks() && tried < 24 && !found; b++) {
                 if (ba.free_cnt[b] < k) continue;
                 tried++;
+                // x fits iff used[x ^ c] is clear for every child byte c: OR the block's mask permuted by each
+                // c (bit x of the permuted mask = bit x ^ c of the mask) and take the lowest clear bit
                 const uint64_t* u = &ba.used[(size_t)b * 4];
-                for (uint32_t x = 0; x < 256 && !found; x++) {
-                    bool ok = true;
-                    for (uint32_t j = lo; j < hi; j++) {
-                        uint32_t t = x ^ edges[j].byte;
-                        if ((u[t >> 6] >> (t & 63)) & 1ULL) {
-                            ok = false;
-                            break;
-                        }
-                    }
-                    if (ok) {
-                        chosen = (b << 8) | x;
-                        found = true;
+                uint64_t forbidden[4] = {0, 0, 0, 0};
+                for (uint32_t j = lo; j < hi; j++) {
+                    const uint32_t c = edges[j].byte;
+                    for (uint32_t w = 0; w < 4; w++) {
+                        uint64_t v = u[w ^ (c >> 6)];
+                        if (c & 1u) v = ((v >> 1) & 0x5555555555555555ULL) | ((v & 0x5555555555555555ULL) << 1);
+                        if (c & 2u) v = ((v >> 2) & 0x3333333333333333ULL) | ((v & 0x3333333333333333ULL) << 2);
+                        if (c & 4u) v = ((v >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((v & 0x0F0F0F0F0F0F0F0FULL) << 4);
+                        if (c & 8u) v = ((v >> 8) & 0x00FF00FF00FF00FFULL) | ((v & 0x00FF00FF00FF00FFULL) << 8);
+                        if (c & 16u) v = ((v >> 16) & 0x0000FFFF0000FFFFULL) | ((v & 0x0000FFFF0000FFFFULL) << 16);
+                        if (c & 32u) v = (v >> 32) | (v << 32);
+                        forbidden[w] |= v;
                     }
                 }
+                for (uint32_t w = 0; w < 4 && !found; w++)
+                    if (~forbidden[w]) {
+                        chosen = (b << 8) | (w * 64u + (uint32_t)__builtin_ctzll(~forbidden[w]));
+                        found = true;
+                    }
             }
             if (!found) {
                 ba.add_block();
