@@ -55,14 +55,13 @@ __device__ __forceinline__ void e4l_fwd_step(double sv, double& acc, double& fin
     acc = sel_f64(MU, cand, acc + cand);     // lane U starts accumulating position p0 + U + 16
 }
 
-// kHotSlots: expected counts of the first (hottest-first order) slots of the reversed trie are summed in
+// Hot slots (P.n_hot): expected counts of the first (hottest-first order) slots of the reversed trie are summed in
 // the block's LDS and flushed once at the end; 2048 slots take about three quarters of all matches, and
-// the global f64 atomics are what bounds the backward kernel.
-constexpr uint32_t kHotSlots = 2048;
+// the global f64 atomics (executed at the memory side, not in L2) are what bounds the backward kernel.
 
 template <int U>
 __device__ __forceinline__ void e4l_bwd_step(double sv, uint32_t hv, double c_cur, double c_nxt, int e_cur, int e_nxt,
-                                             int eb, double* __restrict__ expected_slot, double* hot, bool cold_ok, double& acc) {
+                                             int eb, double* __restrict__ expected_slot, double* hot, uint32_t n_hot, bool cold_ok, double& acc) {
     constexpr uint64_t MU = kRowLane0 << U;
     constexpr uint64_t WRAPPED = (uint64_t)((1u << (U + 1)) - 1u) * kRowLane0;  // lanes l <= U: position y0 + 16 + l
     const double best = row_bcast_f64<U>(acc);  // b[q] of the source (end) position
@@ -71,7 +70,7 @@ __device__ __forceinline__ void e4l_bwd_step(double sv, uint32_t hv, double c_cu
     const int e = (int)sel_u32(WRAPPED, (uint32_t)e_nxt, (uint32_t)e_cur);  // Ea(p) - Ea(n)
     if (sv != 0.0) {  // lattice.rs:305-307
         const double mg = ldexp(cand * c, e + eb);
-        if (hv < kHotSlots)
+        if (hv < n_hot)
             atomicAdd(&hot[hv], mg);  // ds_add_f64
         else if (cold_ok)
             atomicAdd(&expected_slot[hv], mg);
@@ -258,14 +257,15 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie_rev);  // records carry w = exp(score)
     double* hot = reinterpret_cast<double*>(smem);  // kHotSlots partial sums, shared by the block
-    unsigned char* wbase = smem + kHotSlots * 8u + (size_t)wave * (PPL * kE4LEntries * 12u);
+    const uint32_t n_hot = P.n_hot;  // slots summed in LDS (wave-uniform)
+    unsigned char* wbase = smem + n_hot * 8u + (size_t)wave * (PPL * kE4LEntries * 12u);
     double* sc = reinterpret_cast<double*>(wbase);                               // PPL groups of scores
     uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + PPL * kE4LEntries * 8u);  // PPL groups of slots
     // expected counts go to one of n_replicas copies of the slot array (reduced afterwards):
     // a handful of very frequent tokens would otherwise serialise every wave's atomics
     double* __restrict__ expected_slot = P.expected_slot + (size_t)(blockIdx.x % P.n_replicas) * P.n_slots_rev;
     const bool cold_ok = (P.flags & 8u) == 0u;
-    for (uint32_t i = threadIdx.x; i < kHotSlots; i += blockDim.x) hot[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_hot; i += blockDim.x) hot[i] = 0.0;
     __syncthreads();
 
     uint32_t s = 0, n = 0, y0 = 0, smp = 0;
@@ -405,22 +405,22 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
             double sv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) sv[u] = scr[u * 16];
-            e4l_bwd_step<0>(sv[0], hlr[0 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<1>(sv[1], hlr[1 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<2>(sv[2], hlr[2 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<3>(sv[3], hlr[3 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<4>(sv[4], hlr[4 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<5>(sv[5], hlr[5 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<6>(sv[6], hlr[6 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<7>(sv[7], hlr[7 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<8>(sv[8], hlr[8 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<9>(sv[9], hlr[9 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<10>(sv[10], hlr[10 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<11>(sv[11], hlr[11 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<12>(sv[12], hlr[12 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<13>(sv[13], hlr[13 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<14>(sv[14], hlr[14 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
-            e4l_bwd_step<15>(sv[15], hlr[15 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, cold_ok, acc);
+            e4l_bwd_step<0>(sv[0], hlr[0 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<1>(sv[1], hlr[1 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<2>(sv[2], hlr[2 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<3>(sv[3], hlr[3 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<4>(sv[4], hlr[4 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<5>(sv[5], hlr[5 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<6>(sv[6], hlr[6 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<7>(sv[7], hlr[7 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<8>(sv[8], hlr[8 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<9>(sv[9], hlr[9 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<10>(sv[10], hlr[10 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<11>(sv[11], hlr[11 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<12>(sv[12], hlr[12 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<13>(sv[13], hlr[13 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<14>(sv[14], hlr[14 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<15>(sv[15], hlr[15 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
             const int e = row_max_exponent(acc);
             if (e > -100000) {
                 acc = ldexp(acc, -e);
@@ -442,8 +442,8 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
         }
     }
     __syncthreads();
-    const uint32_t n_hot = P.n_slots_rev < kHotSlots ? P.n_slots_rev : kHotSlots;
-    for (uint32_t i = threadIdx.x; i < n_hot; i += blockDim.x) {
+    const uint32_t n_flush = P.n_slots_rev < n_hot ? P.n_slots_rev : n_hot;
+    for (uint32_t i = threadIdx.x; i < n_flush; i += blockDim.x) {
         const double v = hot[i];
         if (v != 0.0) atomicAdd(&expected_slot[i], v);
     }
@@ -484,11 +484,23 @@ hipError_t launch_estep4l_fwd(const Estep4Params& p, int ppl, uint32_t num_cus, 
     return hipGetLastError();
 }
 // backward: ONE block per CU: 12 / 6 / 3 waves x 12 KiB * ppl of match buffers + 16 KiB of hot-slot sums = 160 KiB
-hipError_t launch_estep4l_bwd(const Estep4Params& p, int ppl, uint32_t num_cus, hipStream_t stream) {
-    const uint32_t waves = 12u / (uint32_t)ppl;
+hipError_t launch_estep4l_bwd(const Estep4Params& p0, int ppl, uint32_t num_cus, hipStream_t stream) {
+    // groups of 16 positions per block: 12 (x 12 KiB of match buffer) leave 16 KiB = 2048 hot slots; fewer
+    // groups, more slots summed in LDS instead of memory-side atomics (about 30 G scattered f64 adds per second
+    // chip-wide, whatever their locality).  With 2 positions per lane — picked for passes bound by the serial
+    // chain of their longest snippets, where waves are not what is missing — 8 groups and 8192 slots:
+    // 23.2 -> 20.9 ms per 256 MiB (tools/bwd_groups_sweep.py; TGX_BWD_GROUPS overrides).
+    uint32_t groups = ppl == 2 ? 8 : 12;
+    if (const char* e = getenv("TGX_BWD_GROUPS")) {
+        const int v = atoi(e);
+        if (v >= 4 && v <= 12) groups = (uint32_t)v;
+    }
+    Estep4Params p = p0;
+    const uint32_t waves = std::max(1u, groups / (uint32_t)ppl);
+    p.n_hot = (160u * 1024u - waves * (uint32_t)ppl * kE4LEntries * 12u) / 8u;
     const uint64_t want = (p.n_snips + 4 * waves - 1) / (4 * waves);
     const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus ? (want ? want : 1) : (uint64_t)num_cus);
-    const uint32_t lds = kHotSlots * 8u + waves * (uint32_t)ppl * kE4LEntries * 12u;
+    const uint32_t lds = p.n_hot * 8u + waves * (uint32_t)ppl * kE4LEntries * 12u;
     hipLaunchKernelGGL(pick_bwd(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * waves), lds, stream, p);
     return hipGetLastError();
 }

@@ -99,6 +99,7 @@ struct Estep4Params {
                                     // alpha values, snippet k's blocks at (soffs[k] >> 4) + k
     double* expected_slot;          // f64[n_replicas][n_slots_rev]
     uint32_t n_slots_rev, n_replicas;
+    uint32_t n_hot;                 // estep4l_bwd_kernel: slots summed in the block's LDS (set by its launcher)
     double* logz_sum;
     unsigned long long* err_snip;   // min snippet whose z is not normal (init ~0)
     uint32_t flags;                 // timing experiments only (TGX_FLAGS with TGX_DEBUG=1): 8 = no cold-slot atomics

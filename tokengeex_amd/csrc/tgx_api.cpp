@@ -1237,7 +1237,9 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     {
         const double longest = K ? (double)(soffs[order[0] + 1] - soffs[order[0]]) / 65536.0 : 0.0;
         const double f_gbps[3] = {52.0, 48.0, 33.0}, f_chain[3] = {14.5, 11.0, 9.0};
-        const double b_gbps[3] = {21.0, 16.0, 11.0}, b_chain[3] = {29.0, 23.0, 23.5};
+        // (the backward kernel with 2 positions per lane runs 8 groups of 16 positions per block and sums 8192
+        // slots in LDS: tools/bwd_groups_sweep.py)
+        const double b_gbps[3] = {21.0, 12.7, 11.0}, b_chain[3] = {29.0, 20.9, 23.5};
         double bf = 0, bb = 0;
         for (int i = 0; i < 3; i++) {
             const double tf = std::max((double)N / (f_gbps[i] * 1e6), longest * f_chain[i]);
