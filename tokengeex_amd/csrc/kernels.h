@@ -61,11 +61,11 @@ struct EstepParams {
     uint64_t seed;
 };
 
-hipError_t launch_pair_keys(const uint32_t* ids, const uint64_t* out_offs, uint64_t n_samples,
-                            unsigned long long* keys, uint32_t blocks, hipStream_t stream);
+hipError_t launch_pair_keys(const uint32_t* ids, const uint64_t* out_offs, uint64_t n_samples, uint32_t shift,
+                            unsigned long long sentinel, unsigned long long* keys, uint32_t blocks, hipStream_t stream);
 hipError_t pair_sort_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t pair_sort(void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out,
-                     uint64_t n, hipStream_t stream);
+                     uint64_t n, unsigned int end_bit, hipStream_t stream);
 hipError_t pair_rle_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t pair_rle(void* temp, size_t temp_bytes, const unsigned long long* sorted, uint64_t n,
                     unsigned long long* unique_out, unsigned int* counts_out, unsigned int* n_runs_out,

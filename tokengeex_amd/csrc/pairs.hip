@@ -16,12 +16,13 @@
 
 namespace tgx {
 
-constexpr unsigned long long kPairSentinel = ~0ULL;  // ids are < 2^32 - 1, never a real pair
-
-// keys[o + i] = (ids[o+i] << 32) | ids[o+i+1] for i < cnt - 1 (merge.rs:60-63), sentinel for i = cnt - 1
+// keys[o + i] = (ids[o+i] << shift) | ids[o+i+1] for i < cnt - 1 (merge.rs:60-63), `sentinel` (larger than any
+// pair) for i = cnt - 1.  shift = bits of the largest id: the radix sort then runs over 2 shift + 1 bits instead
+// of 64 (31 bits, four passes instead of eight, for a 32 000-entry vocabulary).
 __global__ __launch_bounds__(256) void pair_keys_kernel(const uint32_t* __restrict__ ids,
                                                         const uint64_t* __restrict__ out_offs,
-                                                        uint64_t n_samples,
+                                                        uint64_t n_samples, uint32_t shift,
+                                                        unsigned long long sentinel,
                                                         unsigned long long* __restrict__ keys) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
@@ -31,14 +32,14 @@ __global__ __launch_bounds__(256) void pair_keys_kernel(const uint32_t* __restri
         const uint64_t cnt = out_offs[s + 1] - o;
         for (uint64_t i = lane; i < cnt; i += 64) {
             const unsigned long long a = ids[o + i];
-            keys[o + i] = (i + 1 < cnt) ? ((a << 32) | (unsigned long long)ids[o + i + 1]) : kPairSentinel;
+            keys[o + i] = (i + 1 < cnt) ? ((a << shift) | (unsigned long long)ids[o + i + 1]) : sentinel;
         }
     }
 }
 
-hipError_t launch_pair_keys(const uint32_t* ids, const uint64_t* out_offs, uint64_t n_samples,
-                            unsigned long long* keys, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(pair_keys_kernel, dim3(blocks), dim3(256), 0, stream, ids, out_offs, n_samples, keys);
+hipError_t launch_pair_keys(const uint32_t* ids, const uint64_t* out_offs, uint64_t n_samples, uint32_t shift,
+                            unsigned long long sentinel, unsigned long long* keys, uint32_t blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(pair_keys_kernel, dim3(blocks), dim3(256), 0, stream, ids, out_offs, n_samples, shift, sentinel, keys);
     return hipGetLastError();
 }
 
@@ -50,8 +51,8 @@ hipError_t pair_sort_temp_bytes(uint64_t n, size_t* bytes) {
     return e;
 }
 hipError_t pair_sort(void* temp, size_t temp_bytes, const unsigned long long* in, unsigned long long* out,
-                     uint64_t n, hipStream_t stream) {
-    return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, 64, stream);
+                     uint64_t n, unsigned int end_bit, hipStream_t stream) {
+    return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0, end_bit, stream);
 }
 hipError_t pair_rle_temp_bytes(uint64_t n, size_t* bytes) {
     unsigned long long* p = nullptr;

@@ -1008,12 +1008,18 @@ static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pai
         pool_alloc(m->device, std::max(tb1, tb2) + 256, &d_temp) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (pair scan)"));
     const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((S + 3) / 4, (uint64_t)m->num_cus * 8));
+    // pair keys of 2 shift (+ 1 for the sentinel) bits, shift = bits of the largest id; widened to the API's
+    // (a << 32) | b on the host
+    uint32_t shift = 1;
+    while (shift < 32 && (1ull << shift) < (unsigned long long)m->vocab_size) shift++;
+    const unsigned long long sentinel = shift < 32 ? (1ull << (2 * shift)) : ~0ULL;
+    const unsigned int end_bit = shift < 32 ? 2 * shift + 1 : 64;
     time_begin(m, "pair_keys_kernel");
-    if (tgx::launch_pair_keys(r->d_ids, r->d_offs, S, d_keys, blocks, m->stream) != hipSuccess)
+    if (tgx::launch_pair_keys(r->d_ids, r->d_offs, S, shift, sentinel, d_keys, blocks, m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "pair key launch failed"));
     time_end(m);
     time_begin(m, "pair_sort+rle");
-    if (tgx::pair_sort(d_temp, tb1, d_keys, d_sorted, T, m->stream) != hipSuccess ||
+    if (tgx::pair_sort(d_temp, tb1, d_keys, d_sorted, T, end_bit, m->stream) != hipSuccess ||
         tgx::pair_rle(d_temp, tb2, d_sorted, T, d_unique, d_cnt, d_runs, m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "pair sort / run-length encode failed"));
     time_end(m);
@@ -1025,7 +1031,7 @@ static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pai
     unsigned long long last_key = 0;
     if (runs && hipMemcpy(&last_key, d_unique + (runs - 1), 8, hipMemcpyDeviceToHost) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "D2H copy failed"));
-    if (runs && last_key == ~0ULL) runs--;
+    if (runs && last_key == sentinel) runs--;
     const unsigned long long* src_keys = d_unique;
     const unsigned int* src_cnt = d_cnt;
     if (n_total) *n_total = runs;
@@ -1056,8 +1062,9 @@ static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pai
         return cleanup(fail(TGX_ERR_DEVICE, "D2H copy of pair table failed"));
     uint64_t* ok = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
     uint64_t* oc = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
+    const unsigned long long low = shift < 32 ? (1ull << shift) - 1 : 0xFFFFFFFFull;
     for (unsigned int i = 0; i < runs; i++) {
-        ok[i] = hk[i];
+        ok[i] = ((hk[i] >> shift) << 32) | (hk[i] & low);
         oc[i] = hc[i];
     }
     *keys = ok;
