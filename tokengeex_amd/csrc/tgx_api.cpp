@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -160,7 +162,7 @@ struct tgx_result {
     uint64_t n_samples = 0, n_tokens = 0;
     uint32_t* d_ids = nullptr;
     uint64_t* d_offs = nullptr;
-    std::vector<uint32_t> h_ids;
+    std::unique_ptr<uint32_t[]> h_ids;  // uninitialised: a vector would zero a GB first
     std::vector<uint64_t> h_offs;
     bool have_ids = false, have_offs = false;
 };
@@ -849,17 +851,21 @@ uint64_t tgx_result_num_tokens(const tgx_result* r) { return r ? r->n_tokens : 0
 const uint32_t* tgx_result_ids(tgx_result* r) {
     if (!r) return nullptr;
     if (!r->have_ids) {
-        r->h_ids.resize(r->n_tokens ? r->n_tokens : 1);
+        r->h_ids.reset(new (std::nothrow) uint32_t[r->n_tokens ? r->n_tokens : 1]);
+        if (!r->h_ids) {
+            fail(TGX_ERR_DEVICE, "out of host memory (ids)");
+            return nullptr;
+        }
         if (r->n_tokens) {
             (void)hipSetDevice(r->device);
-            if (hipMemcpy(r->h_ids.data(), r->d_ids, r->n_tokens * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            if (hipMemcpy(r->h_ids.get(), r->d_ids, r->n_tokens * 4, hipMemcpyDeviceToHost) != hipSuccess) {
                 fail(TGX_ERR_DEVICE, "D2H copy of ids failed");
                 return nullptr;
             }
         }
         r->have_ids = true;
     }
-    return r->h_ids.data();
+    return r->h_ids.get();
 }
 
 const uint64_t* tgx_result_offsets(tgx_result* r) {
