@@ -151,7 +151,7 @@ def main() -> None:
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             out["cpu_baseline"] = cpu_baseline(toks, scores, flat, offs, model, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
