@@ -34,14 +34,28 @@ def main() -> None:
     ap.add_argument("--vocab", type=int, default=32000)
     ap.add_argument("--max-token-length", type=int, default=16)
     ap.add_argument("--kind", default="mixed", choices=["mixed", "ascii"])
+    ap.add_argument("--max-sample-len", type=int, default=65536, help="longest sample of the synthetic corpus, bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive tgx_encode_batch measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 and the ranks meet over gloo")
+    ap.add_argument("--master-port", type=int, default=29533)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Launched bare (`python bench.py --gpus N`): start the N ranks ourselves, one fresh process per
+        # GPU under torch.distributed.run, BEFORE this process imports torch or touches HIP (a process that
+        # has initialised the GPU must never exec or fork workers), relay their output and exit with their code.
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
 
     import numpy as np
@@ -56,15 +70,19 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29533")
         import torch.distributed as dist_mod
         dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.single_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
         dist.barrier()
 
     import tokengeex_amd as tgx
     from tokengeex_amd import synth
 
-    dev = local_rank
+    dev = 0 if args.single_device else local_rank
+    coll_dev = "cpu" if args.single_device else f"cuda:{dev}"  # where the timing collectives' tensors live
     if tgx.device_count() <= dev:
         raise SystemExit("bench.py needs a GPU (no usable HIP device); there is no CPU fallback")
 
@@ -72,7 +90,7 @@ def main() -> None:
     t0 = time.time()
     vflat, _ = synth.make_corpus(4 << 20, args.kind, seed_offset=0)
     toks, scores = synth.build_vocab(vflat[: 2 << 20], args.vocab, args.max_token_length)
-    flat, offs = synth.make_corpus(args.size_mb << 20, args.kind, seed_offset=1000 + rank)
+    flat, offs = synth.make_corpus(args.size_mb << 20, args.kind, max_len=args.max_sample_len, seed_offset=1000 + rank)
     n_bytes, n_samples = int(flat.size), int(offs.size - 1)
     model = tgx.NativeModel(toks, scores, device=dev)
     corpus = tgx.NativeCorpus(flat, offs, device=dev)
@@ -104,26 +122,50 @@ def main() -> None:
     alg_bytes = model.last_algorithmic_bytes()
 
     from tokengeex_amd import dist as tdist
-    max_elapsed, tot_bytes, tot_tokens = tdist.aggregate_timing(elapsed, n_bytes, n_tokens, dist, f"cuda:{dev}")
+    max_elapsed, tot_bytes, tot_tokens = tdist.aggregate_timing(elapsed, n_bytes, n_tokens, dist, coll_dev)
+
+    # ---- PCIe-inclusive rate of the host-buffer entry point (tgx_encode_batch + copies of ids and offsets
+    # into caller memory), rank 0 only, after the timed region.  Reported as `e2e_mb_s`, never as `value`.
+    e2e = None
+    if rank == 0 and not args.no_e2e:
+        best = None
+        ids_buf = np.empty(int(n_tokens) + 16, np.uint32)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = model.encode_batch_flat(flat, offs)
+            res.ids_into(ids_buf)
+            res.offsets()
+            res.free()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        e2e = {"e2e_mb_s": round(n_bytes / best / 1e6, 2), "e2e_ms": round(best * 1e3, 3)}
+
+    if dist is not None:
+        dist.barrier()  # every rank is done with its device work; only rank 0 goes on (CPU leg, the line)
 
     if rank == 0:
         steps = max(1, args.steps)
         ms_per_step = max_elapsed / steps * 1e3
         mb_s = tot_bytes * steps / max_elapsed / 1e6
-        dom = max(kernel_ms, key=kernel_ms.get) if kernel_ms else "encode_kernel"
-        dom_ms = kernel_ms.get(dom, 0.0) / steps
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel from the PMC passes of this workload
-        # (tools/pmc_traffic.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, gfx950 x2 fetch
-        # correction); counters cannot be read from inside this process, so the committed figure of the
-        # last profiled run is reported, and only for the workload it was taken on
-        traffic = None
-        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01")
-        tpath = next((t for t in (os.path.join(pdir, n) for n in ("m_final_pmc_traffic.json", "h_final_pmc_traffic.json"))
-                      if os.path.exists(t)), "")
-        if tpath and (args.size_mb, args.vocab, args.kind, args.max_token_length) == (1024, 32000, "mixed", 16):
+        per_step = {k: v / steps for k, v in kernel_ms.items()}
+        dom = max(per_step, key=per_step.get) if per_step else "encode_kernel"
+        dom_ms = per_step.get(dom, 0.0)
+        pass_ms = sum(per_step.values())
+        # roofline: the pass's algorithmic bytes (N + 4 T + 16 (S + 1)) belong to the
+        # whole kernel sequence of a pass, so they are divided by the SUM of its kernels' times (HIP events on
+        # the library's stream); the dominant kernel and its own time are named beside it.
+        achieved = alg_bytes / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+        # HBM bytes per pass from the rocprofv3 PMC passes of this workload (tools/pmc_traffic.sh; counters
+        # cannot be read inside this process): the committed figure of the profiled build, with its source
+        # named, and only for the workload it was taken on; null otherwise
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+        if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length, args.max_sample_len) == (1024, 32000, "mixed", 16, 65536):
             with open(tpath) as f:
-                traffic = json.load(f).get(dom.split("<")[0], {}).get("hbm_bytes_per_launch_corrected")
+                tj = json.load(f)
+            if set(tj.get("kernels", {})) == {k.split("<")[0] for k in per_step}:  # same kernel sequence as this build
+                traffic = tj.get("hbm_bytes_per_pass_corrected")
+                traffic_source = f"profiles/r02/pmc_traffic.json ({tj.get('commit', '?')})"
         out = {
             "metric": "MB/s raw bytes encoded (and tokens/s) at 32K/64K vocab, 1/2/4/8 GPUs",
             "value": round(mb_s, 2),
@@ -139,24 +181,28 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"encode_ordinary_batch, {args.vocab} vocab (max token {args.max_token_length} B), "
-                            f"{args.size_mb} MiB {args.kind} corpus per GPU, ids bit-exact vs CPU oracle",
+                            f"{args.size_mb} MiB {args.kind} corpus per GPU (samples <= {args.max_sample_len} B), "
+                            f"ids bit-exact vs CPU oracle",
                 "bytes_per_gpu": n_bytes, "samples_per_gpu": n_samples, "tokens_per_gpu": int(n_tokens),
                 "parallelism": f"dp{world} (samples sharded, no collective)",
             },
             "mib_per_s": round(tot_bytes * steps / max_elapsed / 1048576.0, 2),
             "tokens_per_s": round(tot_tokens * steps / max_elapsed, 1),
-            "kernel_ms_per_step": {k: round(v / steps, 3) for k, v in kernel_ms.items()},
+            "kernel_ms_per_step": {k: round(v, 3) for k, v in per_step.items()},
             "setup_s": round(setup_s, 1),
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": round(dom_ms, 3), "pass_kernels_ms": round(pass_ms, 3),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
+        if e2e:
+            out.update(e2e)
+        if not args.no_cpu_baseline:  # rank 0 only; the other ranks have left the timed region
             out["cpu_baseline"] = cpu_baseline(toks, scores, flat, offs, model, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
     if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -191,10 +237,18 @@ def cpu_baseline(toks, scores, flat, offs, model, target_seconds: float) -> dict
     res.free()
     if not same:
         raise SystemExit("PARITY FAILURE: GPU token ids differ from the CPU oracle on the baseline sample")
+    # the same port on ONE thread (configs[0]'s "single thread" reading), on ~1/6 of the time budget
+    k1 = int(np.searchsorted(offs, max(1 << 20, int(rate / cores * target_seconds / 6))))
+    k1 = max(1, min(k1, k))
+    t = time.perf_counter()
+    ora.encode_batch_flat(flat[: int(offs[k1])], offs[: k1 + 1], threads=1)
+    dt1 = time.perf_counter() - t
     return {"value": round(float(sub_flat.size) / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": "port",
             "sample": f"first {k} samples ({sub_flat.size} bytes) of the same corpus, {cores} threads, "
                       f"{dt:.1f} s; GPU ids on this sample bit-exact: {same}",
-            "tokens_per_s": round(float(ids.size) / dt, 1)}
+            "tokens_per_s": round(float(ids.size) / dt, 1),
+            "value_1thread": round(float(offs[k1]) / dt1 / 1e6, 2),
+            "sample_1thread": f"first {k1} samples ({int(offs[k1])} bytes), 1 thread, {dt1:.1f} s"}
 
 
 if __name__ == "__main__":

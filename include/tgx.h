@@ -105,6 +105,15 @@ uint64_t tgx_flat_trie_search(const tgx_flat_trie *t, const uint8_t *s, uint64_t
                               uint32_t *lens, uint64_t cap);
 void tgx_flat_trie_stats(const tgx_flat_trie *t, uint64_t *n_slots, uint64_t *n_nodes,
                          uint32_t *max_token_len);
+/* The same search over the 8-byte label-checked records encode5_kernel walks (built from the same slot
+ * assignment: the walk keeps only `base` and compares a record's label with the text byte), plus figures of
+ * its score table: *n_hot distinct score values in the table of at most max_hot, *n_cold terminal slots whose
+ * value is outside it, *hot_coverage the expected share of matches the table serves.  Any out pointer may be
+ * NULL.  Returns the number of matches, or UINT64_MAX when the records cannot be built (>= 2^23 slots). */
+uint64_t tgx_flat_trie_search8(const tgx_flat_trie *t, const uint8_t *bytes, const uint64_t *offs,
+                               const double *scores, uint32_t max_hot, const uint8_t *s, uint64_t n,
+                               uint32_t *ids, uint32_t *lens, uint64_t cap, uint32_t *n_hot,
+                               uint64_t *n_cold, double *hot_coverage);
 /* copies the slot table: check[n_slots], base_flags[n_slots] (bit 31 = terminal), tokid[n_slots] */
 void tgx_flat_trie_copy(const tgx_flat_trie *t, uint32_t *check, uint32_t *base_flags, uint32_t *tokid);
 /* Builds the token-bytes -> id table the trace kernel probes and looks every token up again through it

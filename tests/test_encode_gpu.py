@@ -192,12 +192,13 @@ def test_both_kernel_paths_agree(monkeypatch):
     flat, offs, toks, scores = corpus_and_vocab(1 << 20, "mixed", 5000, 16, seed_offset=3)
     nat, ora = _pair(toks, scores)
     want_ids, want_offs = ora.encode_batch_flat(flat, offs, threads=8)
-    for path in ("rows4", "fused"):
+    for path in ("rows5", "rows4", "fused"):
         monkeypatch.setenv("TGX_PATH", path)
         res = nat.encode_batch_flat(flat, offs)
         np.testing.assert_array_equal(res.ids(), want_ids)
         np.testing.assert_array_equal(res.offsets(), want_offs)
         assert ("encode4_kernel" in nat.last_kernel_times()) == (path == "rows4")
+        assert ("encode5_kernel" in nat.last_kernel_times()) == (path == "rows5")
 
 
 def test_non_finite_scores_use_the_exact_generic_path():
@@ -212,28 +213,33 @@ def test_non_finite_scores_use_the_exact_generic_path():
         assert "encode4_kernel" not in nat.last_kernel_times()
 
 
-def test_launch_geometry_fits_the_device(monkeypatch):
-    """The four-samples-per-wave kernel must really have its planned waves resident: two blocks of nine or
-    ten waves put six waves on some SIMD, which needs the kernel to stay within 80 VGPRs (a build that
+@pytest.mark.parametrize("path,kernel,min_waves", [("rows5", "encode5_kernel", 24), ("rows4", "encode4_kernel", 18)])
+def test_launch_geometry_fits_the_device(monkeypatch, path, kernel, min_waves):
+    """The four-samples-per-wave kernels must really have their planned waves resident: two blocks of nine or
+    ten waves put six waves on some SIMD, which needs encode4_kernel to stay within 80 VGPRs (a build that
     drifted to 82 ran at half occupancy, 28 ms instead of 18 ms per GiB, without failing any parity test)."""
     flat, offs, toks, scores = corpus_and_vocab(8 << 20, "mixed", 4000, 16, max_len=2048)
     nat = tgx.NativeModel(toks, scores)
     monkeypatch.setenv("TGX_PPL", "1")       # one position per lane: the bench's variant, whatever the corpus shape
+    monkeypatch.setenv("TGX_PATH", path)
     res = nat.encode_batch_flat(flat, offs)
     res.free()
-    assert "encode4_kernel" in nat.last_kernel_times()
-    assert nat.last_encode_waves_per_cu() >= 18
+    assert kernel in nat.last_kernel_times()
+    assert nat.last_encode_waves_per_cu() >= min_waves
 
 
+@pytest.mark.parametrize("path", ["rows5", "rows4"])
 @pytest.mark.parametrize("ppl", ["1", "2", "4"])
-def test_every_positions_per_lane_variant(monkeypatch, ppl):
-    """encode4_kernel exists for 1, 2 and 4 positions per lane (the host normally picks by corpus shape): each
-    bit-exact against the oracle, with samples that end on and off block boundaries, with and without dropout."""
+def test_every_positions_per_lane_variant(monkeypatch, ppl, path):
+    """encode5_kernel and encode4_kernel exist for 1, 2 and 4 positions per lane (the host normally picks by
+    corpus shape): each bit-exact against the oracle, with samples that end on and off block boundaries, with
+    and without dropout."""
     monkeypatch.setenv("TGX_PPL", ppl)
+    monkeypatch.setenv("TGX_PATH", path)
     flat, offs, toks, scores = corpus_and_vocab(512 << 10, "mixed", 3000, 16, seed_offset=23, max_len=20000)
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
     assert_same_encoding(nat, ora, flat, offs)
-    assert "encode4_kernel" in nat.last_kernel_times()
+    assert ("encode5_kernel" if path == "rows5" else "encode4_kernel") in nat.last_kernel_times()
     assert_same_encoding(nat, ora, flat, offs, dropout=0.2, seed=5)
     texts = [b"", b"a", b"ab" * 8, b"ab" * 8 + b"c", b"ab" * 16, b"ab" * 32, b"ab" * 32 + b"a", b"hello world " * 30]
     f2, o2 = tgx.pack(texts)

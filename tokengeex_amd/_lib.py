@@ -39,6 +39,8 @@ SYMBOLS = {
     "tgx_flat_trie_build": (_i, [_vp, _vp, _vp, _u32, _pvp]),
     "tgx_flat_trie_free": (None, [_vp]),
     "tgx_flat_trie_search": (_u64, [_vp, _vp, _u64, _vp, _vp, _u64]),
+    "tgx_flat_trie_search8": (_u64, [_vp, _vp, _vp, _vp, _u32, _vp, _u64, _vp, _vp, _u64, C.POINTER(C.c_uint32), _pu64,
+                                     C.POINTER(C.c_double)]),
     "tgx_flat_trie_stats": (None, [_vp, _pu64, _pu64, C.POINTER(C.c_uint32)]),
     "tgx_flat_trie_copy": (None, [_vp, _vp, _vp, _vp]),
     "tgx_tok_hash_selftest": (_i, [_vp, _vp, _u32, C.POINTER(C.c_uint32), _pu64]),
@@ -164,6 +166,14 @@ class NativeResult:
         out = np.empty(t, np.uint32)   # the device copy lands in the array itself
         check(lib.tgx_result_copy_ids(self._h, ptr(out), t))
         return out
+
+    def ids_into(self, out: np.ndarray) -> int:
+        """Copies the ids into caller memory (uint32, at least num_tokens long); -> number of ids."""
+        t = self.num_tokens
+        assert out.dtype == np.uint32 and out.flags.c_contiguous and out.size >= t
+        if t:
+            check(lib.tgx_result_copy_ids(self._h, ptr(out), t))
+        return t
 
     def ids_device_ptr(self) -> int:
         return lib.tgx_result_ids_device(self._h) or 0
@@ -320,6 +330,20 @@ class FlatTrie:
         check(lib.tgx_flat_trie_build(ptr(flat) if flat.size else None, ptr(offs), ptr(sc), len(tokens),
                                       C.byref(h)))
         self._h = h
+        self._flat, self._offs, self._sc = flat, offs, sc
+
+    def common_prefix_search8(self, s: bytes, max_hot: int = 6600):
+        """The search over the 8-byte label-checked records of encode5_kernel -> (matches, stats)."""
+        buf = np.frombuffer(s, dtype=np.uint8)
+        cap = len(s) + 1
+        ids, lens = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        nh, nc, cov = C.c_uint32(), C.c_uint64(), C.c_double()
+        k = lib.tgx_flat_trie_search8(self._h, ptr(self._flat) if self._flat.size else None, ptr(self._offs), ptr(self._sc),
+                                      max_hot, ptr(buf) if len(s) else None, len(s), ptr(ids), ptr(lens), cap,
+                                      C.byref(nh), C.byref(nc), C.byref(cov))
+        if k == 2**64 - 1:
+            raise TokenGeeXError("8-byte records need fewer than 2^23 slots")
+        return [(int(ids[i]), int(lens[i])) for i in range(k)], {"n_hot": nh.value, "n_cold": nc.value, "hot_coverage": cov.value}
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -1,0 +1,407 @@
+// encode5_kernel (gfx950 / CDNA4, wave64): Model::encode (reference src/model.rs:59-129) for vocabularies
+// whose tokens have at most 16 bytes and finite scores — four samples per wave on 16-lane rows like
+// encode4_kernel (kernels.hip), with two changes that attack what bounded that kernel (DESIGN.md section 6:
+// the texture-address path at 1.6 cycles per 16-byte gather lane, and 8 KiB of LDS per wave and 64
+// positions capping the waves per CU):
+//
+//   * 8-byte label-checked trie records (trie_build.h: Trie8Rec).  A walk keeps only `base`; a step is one
+//     8-byte gather {label | terminal | next base, score reference} (0.9 cycles per lane, measured:
+//     profiles/r02/a_gather2.txt) and one compare of the label with the text byte.
+//   * scores are not carried through the match buffer.  The distinct score VALUES of the vocabulary (a few
+//     thousand for generate-style vocabularies, which score tokens by integer counts) sit in a table in
+//     the block's LDS, ordered by how often their tokens are expected to match; the match buffer holds 2-byte
+//     LDS addresses of table entries ("no token" = the address of a -inf entry), 2 KiB per wave and 64
+//     positions instead of 8 KiB.  A token whose value did not make the table ("cold") gets an entry of a
+//     small per-wave pool, filled from HBM while the walk goes on; a wave whose pool runs out marks the samples
+//     it is working on, and the host redoes exactly those with encode4_kernel.
+//
+// The relaxation is encode4_kernel's (relax4_step: same candidate order, strict '>', forced restart), so the
+// back-pointer bytes and the per-sample status are bit-identical and trace_kernel is shared.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace tgx {
+
+// match-index buffer of one 16-position group: four sample rows of 32 columns x 16 start positions x 2 bytes,
+// row stride 1040 bytes (the 16 extra bytes spread the ds_read_b128 of a lane group over all banks).
+// Entry (start u, len) of row r: r * 1040 + (u + len - 1) * 32 + u * 2, so a walker lane's address is a
+// per-lane constant plus (len - 1) * 32 — an instruction offset, no address arithmetic in the walk.  Lane l of
+// the row, which at step u accumulates end position u + len with len - 1 = (l - u - 1) & 15, finds its entries
+// in column l - 1 (steps u < l) and column l + 15 (steps u >= l); the rows of either column that belong to
+// the other are never written, so OR-ing the two 32-byte columns gives the lane's 16 entries.  Lane 0 reads
+// column 31, which nothing writes.
+constexpr uint32_t kE5RowStride = 1040;
+constexpr uint32_t kE5GroupBytes = 4 * kE5RowStride;  // 4160
+
+// sref of a record (trie_build.h: Trie8Rec): bit 31 terminal, bit 30 cold, low bits LDS byte offset / slot
+constexpr uint32_t kSrefCold = 0x40000000u;
+
+template <int PPL>
+struct WalkCtx {
+    const uint2* __restrict__ trie;
+    const uint2* rootc;
+    unsigned char* smem;
+    const double* __restrict__ cold_scores;
+    uint32_t root_base, pool_entries, pool_off, s, flags;
+    double dropout;
+    uint64_t seed;
+};
+
+// ---- one trie step of all PPL walks of a lane, depth D a compile-time constant (the loop over depths is
+// unrolled by template recursion: with its early exit and the wave-wide pool allocation inside, hipcc's
+// unroller gives up on the plain loop and the text bytes end up selected by v_cndmask chains).
+// COLD = false is the build for vocabularies whose score values all fit the LDS table: no pool code at all.
+template <bool DROPOUT, bool COLD, int PPL, int D>
+struct Walk5 {
+    static __device__ __forceinline__ void run(const WalkCtx<PPL>& W, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
+                                               const uint32_t (&pg)[PPL], unsigned char* const (&wlane)[PPL], bool (&alive)[PPL],
+                                               uint32_t (&base)[PPL], double (&pend_val)[PPL], uint32_t (&pend_addr)[PPL],
+                                               uint32_t& pool_cnt, bool& bad) {
+        constexpr int d = D;
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            alive[g] = alive[g] && ((uint32_t)d < maxd[g]);
+            any = any || alive[g];
+        }
+        if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+        uint2 rec[PPL];
+        uint32_t c[PPL];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            c[g] = (bytes[g][d >> 2] >> ((d & 3) * 8)) & 0xFFu;
+            rec[g] = make_uint2(0u, 0u);
+            if (alive[g]) {  // finished walks issue no load
+                if (d == 0)
+                    rec[g] = W.rootc[(W.root_base ^ c[g]) & 255u];
+                else
+                    rec[g] = W.trie[(W.flags & 8u) ? (c[g] & 1u) : (base[g] ^ c[g])];  // flags: timing experiments only
+            }
+        }
+        if (COLD) {  // cold scores requested one step ago have had this step's issue time to arrive
+#pragma unroll
+            for (int g = 0; g < PPL; ++g)
+                if (pend_addr[g]) {
+                    *reinterpret_cast<double*>(W.smem + pend_addr[g]) = pend_val[g];
+                    pend_addr[g] = 0u;
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            alive[g] = alive[g] && ((rec[g].x & 0xFFu) == c[g]);
+            bool term = alive[g] && (int32_t)rec[g].y < 0;
+            base[g] = rec[g].x >> 8;  // of a finished walk: never used again
+            if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
+                if (term && d >= 1) term = W.dropout < dropout_u01(W.seed, W.s, pg[g], (uint32_t)d + 1u);
+            }
+            uint32_t ref = rec[g].y;
+            if (COLD) {
+                const bool cold = term && (ref & kSrefCold) != 0u;
+                const uint64_t cm = __builtin_amdgcn_ballot_w64(cold);
+                if (cm != 0) {  // wave-uniform
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                    const uint32_t e = pool_cnt + rank;
+                    pool_cnt += (uint32_t)__builtin_popcountll(cm);
+                    if (cold) {
+                        if (e < W.pool_entries) {
+                            pend_val[g] = W.cold_scores[ref & 0x3FFFFFFFu];
+                            pend_addr[g] = W.pool_off + e * 8u;
+                            ref = pend_addr[g];
+                        } else {
+                            ref = 0u;  // dropped: the sample is redone
+                        }
+                    }
+                    if (pool_cnt > W.pool_entries) bad = true;  // every row of the wave: their samples share the pool
+                }
+            }
+            if (term) *reinterpret_cast<uint16_t*>(wlane[g] + d * 32) = (uint16_t)ref;
+        }
+        Walk5<DROPOUT, COLD, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, base, pend_val, pend_addr, pool_cnt, bad);
+    }
+};
+template <bool DROPOUT, bool COLD, int PPL>
+struct Walk5<DROPOUT, COLD, PPL, 16> {
+    static __device__ __forceinline__ void run(const WalkCtx<PPL>&, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL],
+                                               const uint32_t (&)[PPL], unsigned char* const (&)[PPL], bool (&)[PPL], uint32_t (&)[PPL],
+                                               double (&)[PPL], uint32_t (&)[PPL], uint32_t&, bool&) {}
+};
+
+// TGX_STAMPS=1 (diagnostic runs only): s_memtime stamps around the phases of an iteration, summed per wave
+#define E5_STAMP(i)                                                    \
+    if (P.stamps) {                                                    \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        const uint64_t _now = (uint64_t)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                            \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        seg[i] += _now - t_last;                                       \
+        t_last = _now;                                                 \
+    }
+
+template <bool DROPOUT, bool COLD, int PPL>
+__global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode5_kernel(EncodeParams P, Encode5Params Q) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t LM = 16;
+    constexpr uint32_t SPAN = 16u * PPL;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = lane & 15u, r = lane >> 4;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint2* __restrict__ trie = reinterpret_cast<const uint2*>(Q.trie8);
+    // ---- LDS: [0, 8 (n_hot + 1)) score table (entry 0 = -inf) | per-wave pools | root records | match indices
+    double* const score_tab = reinterpret_cast<double*>(smem);
+    const uint32_t pool_off = 8u * (Q.n_hot + 1u) + wave * (Q.pool_entries * 8u);  // this wave's pool, byte offset
+    const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
+    unsigned char* wbase = smem + Q.idx_off + (size_t)wave * (PPL * kE5GroupBytes);
+    {
+        const double ninf_ = -__builtin_huge_val();
+        for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = i ? Q.hot[i - 1u] : ninf_;
+        uint2* rw = reinterpret_cast<uint2*>(smem + Q.root_off);
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
+        __syncthreads();
+    }
+
+    uint32_t s = 0, n = 0, p0 = 0;
+    uint64_t beg = 0;
+    bool live = false, need_new = true, bad = false;
+    const double ninf = -__builtin_huge_val();
+    double acc = ninf;
+    uint32_t bpv = kNoStep;
+    uint32_t wn[4 * PPL + 1];
+    uint32_t pk = 0, pk_j = 0;
+    bool pk_dirty = false;
+#pragma unroll
+    for (int q = 0; q <= 4 * PPL; ++q) wn[q] = 0;
+    // this lane's two 32-byte columns of every group's index buffer (what it reads, and what it resets) and
+    // the entry of its own start position's 1-byte token (what it writes, + 32 bytes per further byte)
+    const uint32_t col_a = r * kE5RowStride + ((l - 1u) & 31u) * 32u, col_b = r * kE5RowStride + (l + 15u) * 32u;
+    const uint32_t wr_off = r * kE5RowStride + l * 34u;
+    uint64_t seg[5] = {0, 0, 0, 0, 0};
+    uint64_t t_last = P.stamps ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
+    uint32_t iters = 0;
+
+    for (;;) {
+        {
+            const uint64_t k = claim_rows(P.queue, need_new, r);
+            if (need_new) {
+                live = k < P.n_samples;
+                if (live) {
+                    s = P.order[k];
+                    beg = P.offs[s];
+                    n = (uint32_t)(P.offs[s + 1] - beg);
+                }
+            }
+        }
+        if (need_new) {
+            p0 = 0;
+            acc = (l == 0u) ? 0.0 : ninf;
+            bpv = kNoStep;
+            pk_dirty = false;
+            bad = false;
+        }
+        const bool fresh_row = need_new;
+        need_new = false;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+        iters++;
+        E5_STAMP(0)  // sample switching
+
+        // ---- text window (as encode4_kernel)
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p0 + l : 0));
+        const uint32_t sh = (uint32_t)(addr & 3u);
+        const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
+        uint32_t w[4 * PPL + 1];
+        if (fresh_row) {
+#pragma unroll
+            for (int q = 0; q <= 4 * PPL; ++q) w[q] = wp[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q <= 4 * PPL; ++q) w[q] = wn[q];
+        }
+        uint32_t bytes[PPL][4];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bytes[g][q] = __builtin_amdgcn_alignbyte(w[4 * g + q + 1], w[4 * g + q], sh);
+
+        // every (start, len) starts as "no token": index 0 = the table's -inf entry
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            uint4* ca = reinterpret_cast<uint4*>(wbase + g * kE5GroupBytes + col_a);
+            uint4* cb = reinterpret_cast<uint4*>(wbase + g * kE5GroupBytes + col_b);
+            ca[0] = make_uint4(0, 0, 0, 0);
+            ca[1] = make_uint4(0, 0, 0, 0);
+            cb[0] = make_uint4(0, 0, 0, 0);
+            cb[1] = make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        E5_STAMP(1)  // text window, reset
+
+        // ---- match: 64 * PPL walks over the 8-byte records
+        uint32_t pg[PPL], maxd[PPL], base[PPL];
+        unsigned char* wlane[PPL];
+        bool alive[PPL];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            pg[g] = p0 + 16u * g + l;
+            const uint32_t rem = (live && pg[g] < n) ? (n - pg[g]) : 0u;
+            maxd[g] = rem < LM ? rem : LM;
+            base[g] = Q.root_base;
+            alive[g] = maxd[g] > 0 && !(P.flags & 1u);
+            wlane[g] = wbase + g * kE5GroupBytes + wr_off;
+        }
+        uint32_t pool_cnt = 0;          // wave-uniform: pool entries handed out in this iteration
+        double pend_val[PPL];           // cold scores on their way from HBM ...
+        uint32_t pend_addr[PPL];        // ... and the pool entries they go to (0 = none)
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            pend_val[g] = 0.0;
+            pend_addr[g] = 0u;
+        }
+        {
+            WalkCtx<PPL> W{trie, rootc, smem, Q.cold_scores, Q.root_base, Q.pool_entries, pool_off, s, P.flags, P.dropout, P.seed};
+            Walk5<DROPOUT, COLD, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, base, pend_val, pend_addr, pool_cnt, bad);
+        }
+        if (COLD) {
+#pragma unroll
+            for (int g = 0; g < PPL; ++g)
+                if (pend_addr[g]) *reinterpret_cast<double*>(smem + pend_addr[g]) = pend_val[g];
+        }
+        __builtin_amdgcn_wave_barrier();
+        E5_STAMP(2)  // walk
+        {   // the following block's text window lands while the relax runs
+            const uint32_t* __restrict__ np = wp + 4 * PPL;
+#pragma unroll
+            for (int q = 0; q <= 4 * PPL; ++q) wn[q] = np[q];
+        }
+
+        // ---- relax: a lane's 16 match indices are its two columns OR-ed; the scores come from the table
+        uint32_t fin[PPL];
+        bool reached[PPL];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            fin[g] = kNoStep;
+            reached[g] = true;
+            if (P.flags & 2u) continue;
+            const uint4* pa = reinterpret_cast<const uint4*>(wbase + g * kE5GroupBytes + col_a);
+            const uint4* pb = reinterpret_cast<const uint4*>(wbase + g * kE5GroupBytes + col_b);
+            const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+            const uint32_t iw[8] = {a0.x | b0.x, a0.y | b0.y, a0.z | b0.z, a0.w | b0.w,
+                                    a1.x | b1.x, a1.y | b1.y, a1.z | b1.z, a1.w | b1.w};
+            double sv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
+                sv[u] = *reinterpret_cast<const double*>(smem + a);
+            }
+            uint32_t fhi = 0xFFF00000u;
+            relax4_step<0>(sv[0], acc, bpv, fin[g], fhi);
+            relax4_step<1>(sv[1], acc, bpv, fin[g], fhi);
+            relax4_step<2>(sv[2], acc, bpv, fin[g], fhi);
+            relax4_step<3>(sv[3], acc, bpv, fin[g], fhi);
+            relax4_step<4>(sv[4], acc, bpv, fin[g], fhi);
+            relax4_step<5>(sv[5], acc, bpv, fin[g], fhi);
+            relax4_step<6>(sv[6], acc, bpv, fin[g], fhi);
+            relax4_step<7>(sv[7], acc, bpv, fin[g], fhi);
+            relax4_step<8>(sv[8], acc, bpv, fin[g], fhi);
+            relax4_step<9>(sv[9], acc, bpv, fin[g], fhi);
+            relax4_step<10>(sv[10], acc, bpv, fin[g], fhi);
+            relax4_step<11>(sv[11], acc, bpv, fin[g], fhi);
+            relax4_step<12>(sv[12], acc, bpv, fin[g], fhi);
+            relax4_step<13>(sv[13], acc, bpv, fin[g], fhi);
+            relax4_step<14>(sv[14], acc, bpv, fin[g], fhi);
+            relax4_step<15>(sv[15], acc, bpv, fin[g], fhi);
+            reached[g] = fhi != 0xFFF00000u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        E5_STAMP(3)  // relax
+
+        // ---- back-pointer bytes (encode4_kernel's packed, permuted layout), next block
+        uint8_t* const bpw = P.bp8 + bp8_base(beg, s);
+#pragma unroll
+        for (int g = 0; g < PPL; ++g)
+            if (live && pg[g] >= 1u && pg[g] <= n) {
+                const uint32_t b = reached[g] ? ((l - fin[g] - 1u) & 15u) : 0xFFu;
+                const uint32_t j = pg[g] - 1u, kq = (j >> 4) & 3u;
+                pk = (kq == 0u) ? b : (pk | (b << (8u * kq)));
+                pk_j = j;
+                pk_dirty = true;
+                if (kq == 3u) {
+                    __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(j) & ~3u)));
+                    pk_dirty = false;
+                }
+            }
+        if (live && n - p0 < SPAN && pk_dirty) {
+            __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(pk_j) & ~3u)));
+            pk_dirty = false;
+        }
+        if (live) {
+            const uint32_t left = n - p0;
+            if (left < SPAN) {
+#pragma unroll
+                for (int g = 0; g < PPL; ++g)
+                    if (left == 16u * g + l) {
+                        P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
+                        if (COLD && bad) {  // a pool overflow touched this sample: encode4_kernel redoes it
+                            const unsigned long long at = atomicAdd(Q.redo_count, 1ull);
+                            Q.redo_list[at] = s;
+                        }
+                    }
+                need_new = true;
+            } else {
+                p0 += SPAN;
+            }
+        }
+        E5_STAMP(4)  // stores, bookkeeping
+    }
+    if (P.stamps && lane == 0) {
+        unsigned long long* o = P.stamps + (size_t)(blockIdx.x * (blockDim.x >> 6) + wave) * 8u;
+        for (int i = 0; i < 5; ++i) o[i] = seg[i];
+        o[5] = iters;
+    }
+}
+
+typedef void (*encode5_fn)(EncodeParams, Encode5Params);
+static encode5_fn pick_encode5(bool dropout, bool cold, int ppl) {
+    if (cold) {
+        if (ppl == 1) return dropout ? encode5_kernel<true, true, 1> : encode5_kernel<false, true, 1>;
+        if (ppl == 2) return dropout ? encode5_kernel<true, true, 2> : encode5_kernel<false, true, 2>;
+        return dropout ? encode5_kernel<true, true, 4> : encode5_kernel<false, true, 4>;
+    }
+    if (ppl == 1) return dropout ? encode5_kernel<true, false, 1> : encode5_kernel<false, false, 1>;
+    if (ppl == 2) return dropout ? encode5_kernel<true, false, 2> : encode5_kernel<false, false, 2>;
+    return dropout ? encode5_kernel<true, false, 4> : encode5_kernel<false, false, 4>;
+}
+
+// LDS of one block of `waves` waves: score table + pools (both below 64 KiB: the match indices are 16-bit
+// addresses), root records, match indices.  Returns 0 when the table and pools do not fit below 64 KiB.
+uint32_t encode5_lds_layout(uint32_t n_hot, uint32_t pool_entries, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off) {
+    const uint32_t score_bytes = 8u * (n_hot + 1u) + (uint32_t)waves * pool_entries * 8u;
+    if (score_bytes > 65536u) return 0;
+    const uint32_t ro = (score_bytes + 15u) & ~15u;
+    const uint32_t io = ro + 2048u;
+    if (root_off) *root_off = ro;
+    if (idx_off) *idx_off = io;
+    return io + (uint32_t)waves * (uint32_t)ppl * kE5GroupBytes;
+}
+
+hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out) {
+    hipFuncAttributes attr;
+    hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(pick_encode5(dropout, cold, ppl)));
+    if (e != hipSuccess) return e;
+    const int regs = (attr.numRegs + 7) & ~7;
+    *out = regs > 0 ? (512 / regs > 8 ? 8 : 512 / regs) : 8;
+    return hipSuccess;
+}
+
+hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
+    const uint32_t lds = encode5_lds_layout(q.n_hot, q.pool_entries, waves, ppl, &q.root_off, &q.idx_off);
+    if (lds == 0 || lds > 160u * 1024u) return hipErrorInvalidValue;
+    encode5_fn fn = pick_encode5(p.dropout > 0.0, cold, ppl);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), lds, stream, p, q);
+    return hipGetLastError();
+}
+
+}  // namespace tgx

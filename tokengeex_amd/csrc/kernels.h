@@ -33,6 +33,18 @@ struct EncodeParams {
     unsigned long long* stamps;     // diagnostic build only (TGX_STAMPS=1): 8 u64 per wave
 };
 
+// encode5_kernel (encode5.hip): 8-byte label-checked records, score values in an LDS table
+struct Encode5Params {
+    const void* trie8;              // Trie8Rec[n_slots]
+    const double* cold_scores;      // f64[n_slots]: score of every terminal slot (values outside the table)
+    const double* hot;              // f64[n_hot]: the table's values, entry i at LDS byte offset 8 (i + 1)
+    uint32_t root_base, n_hot;
+    uint32_t pool_entries;          // per wave: LDS entries for cold values of one iteration
+    uint32_t root_off, idx_off;     // LDS layout (set by the launcher)
+    unsigned long long* redo_count; // samples whose wave ran out of pool entries (init 0) ...
+    uint32_t* redo_list;            // ... and their indices, u32[S]: encode4_kernel redoes exactly those
+};
+
 struct CompactParams {
     const uint64_t* offs;
     const uint32_t* order;
@@ -132,6 +144,9 @@ hipError_t encode4_waves_per_simd(bool dropout, int ppl, bool root, int* out);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream);
 uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
+uint32_t encode5_lds_layout(uint32_t n_hot, uint32_t pool_entries, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off);
+hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out);
+hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip
 hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream);
 hipError_t launch_encode4l(const EncodeParams& p, uint32_t num_cus, hipStream_t stream);  // encode4l.hip

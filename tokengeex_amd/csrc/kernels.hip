@@ -330,32 +330,7 @@ __global__ __launch_bounds__(256) void encode_kernel(EncodeParams P) {
 // later ones only when strictly greater, absent tokens and unreachable sources give
 // cand = -inf and never win.  This needs every vocabulary score to be finite; models
 // with +-inf / NaN scores use the generic kernel instead.
-constexpr uint32_t kNoStep = 0xFFu;  // "nothing pushed into this accumulator yet"
-
-// The winner is remembered as the step U that pushed it; with the lane's own index that
-// gives the token length ((l - U - 1) & 15) + 1, the only thing the trace needs: the
-// token id is looked up from the token's bytes (hash table), so no trie handle travels
-// through LDS and the match buffer is 8 bytes per (position, length).
-//
-// Step U finalises position p0 + U (lane U of each row) and starts position p0 + U + 16 in
-// the same lane.  The final (winner step, high word of the score) pair of that lane is kept
-// in `fin` / `fhi`, and the lane is restarted by FORCING it to take this step's candidate
-// (the 16-byte token starting at p0 + U, or -inf) instead of resetting it first.  A forced
-// take of -inf leaves a meaningless winner step behind; the position is "not reached" iff its
-// final score is -inf, which is what the kept high word tells.  (Parking the pair in LDS with
-// an EXEC-masked store instead of two v_cndmask was tried: the LDS pipe is per CU, the VALUs
-// per SIMD, and the kernel got slower.)
-template <int U>
-__device__ __forceinline__ void relax4_step(double sv, double& acc, uint32_t& bpv, uint32_t& fin, uint32_t& fhi) {
-    constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
-    const double best = row_bcast_f64<U>(acc);
-    fin = sel_u32(MU, bpv, fin);
-    fhi = sel_u32(MU, (uint32_t)((uint64_t)__double_as_longlong(acc) >> 32), fhi);
-    const double cand = best + sv;           // model.rs:98
-    const uint64_t take = __builtin_amdgcn_fcmp(cand, acc, 2 /* OGT: model.rs:101 */) | MU;
-    acc = sel_f64(take, cand, acc);
-    bpv = sel_imm_u32<U>(take, bpv);
-}
+// (kNoStep and relax4_step live in device_common.h: encode5.hip shares them)
 
 // rows4 LDS: 1024 f64 scores (8 KiB) per wave and 16-position group — 20 waves per CU.
 constexpr uint32_t kRows4Entries = 1024;

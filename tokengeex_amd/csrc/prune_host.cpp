@@ -11,9 +11,6 @@
 #include "../../include/tgx.h"
 #include "trie_build.h"
 
-struct tgx_flat_trie {
-    tgx::FlatTrie flat;
-};
 
 namespace {
 

@@ -106,6 +106,10 @@ struct KernelTime {
     bool used;
 };
 constexpr int kMaxTimed = 8;
+// encode5_kernel: values in the LDS score table (the table and the per-wave pools of cold values share the
+// 64 KiB a 16-bit match index can address) and pool entries per wave
+constexpr uint32_t kE5MaxHot = 6600;
+constexpr uint32_t kE5PoolEntries = 64;
 
 }  // namespace
 
@@ -136,6 +140,13 @@ struct tgx_model {
     bool estep_linear_ok = false;   // tables for the linear-domain E-step kernels exist
     tgx::TokHashTable tokhash;      // token bytes -> id (rows4 trace); ok == false: not usable
     void* d_tokhash = nullptr;
+    // encode5_kernel: 8-byte label-checked records + table of distinct score values (trie_build.h: Trie8)
+    void* d_trie8 = nullptr;
+    double* d_cold_scores = nullptr;
+    double* d_hot = nullptr;
+    uint32_t n_hot = 0, root_base8 = 0;
+    bool have_trie8 = false, has_cold = false;
+    double hot_coverage = 0.0;
     int estep_blocks_per_cu = 0;
     KernelTime timed[kMaxTimed] = {};
     int n_timed = 0;
@@ -270,9 +281,113 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     const bool use2 = !use4 && m->lm <= 32 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
     if (debug_on())
         fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u\n",
-                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? "rows4" : (use2 ? "rows2" : "fused"),
+                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? (m->have_trie8 && m->hot_coverage >= 0.85 ? "rows5" : "rows4") : (use2 ? "rows2" : "fused"),
                 m->flat.table.size(), p.root_base);
-    if (use4) {
+    // encode5_kernel (8-byte records, score values in LDS) when the table is expected to serve most matches;
+    // TGX_PATH=rows4 / rows5 force either kernel (A/B timing, tests of both paths)
+    const bool use5 = use4 && m->have_trie8 && !(force && strcmp(force, "rows4") == 0) &&
+                      (m->hot_coverage >= 0.85 || (force && strcmp(force, "rows5") == 0));
+    if (use5) {
+        int ppl = 1;
+        {
+            // positions per lane, as for encode4_kernel below: throughput against the longest sample's chain
+            const double gbps[3] = {60.0, 50.0, 34.0}, chain_ms[3] = {13.5, 10.7, 9.1};
+            double best_t = 0;
+            for (int i = 0; i < 3; i++) {
+                const double t = std::max((double)c->n_bytes / (gbps[i] * 1e6), (double)c->max_len / 65536.0 * chain_ms[i]);
+                if (i == 0 || t < best_t * 0.95) {
+                    best_t = t;
+                    ppl = 1 << i;
+                }
+            }
+        }
+        if (const char* e = getenv("TGX_PPL")) {
+            const int v = atoi(e);
+            if (v == 1 || v == 2 || v == 4) ppl = v;
+        }
+        int per_simd = 0;
+        HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, m->has_cold, ppl, &per_simd));
+        // two blocks per CU, each with half of the waves the registers allow (a block's waves are dealt
+        // round-robin to the four SIMDs); fewer waves until the blocks' LDS fits
+        int bpc = 2, waves = std::min(16, (per_simd / 2) * 4);
+        if (const char* e = getenv("TGX_WAVES")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 16) waves = v;
+        }
+        if (const char* e = getenv("TGX_BPC")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8) bpc = v;
+        }
+        while (waves > 1) {
+            const uint32_t lds = tgx::encode5_lds_layout(m->n_hot, kE5PoolEntries, waves, ppl, nullptr, nullptr);
+            if (lds != 0 && lds * (uint32_t)bpc <= 160u * 1024u) break;
+            waves--;
+        }
+        // whole blocks only: a block's waves are dealt round-robin to the SIMDs, ceil(waves / 4) on the fullest
+        m->last_encode_waves_per_cu = std::min(bpc, per_simd / ((waves + 3) / 4)) * waves;
+        const uint64_t rows_per_block = 4 * (uint64_t)waves;
+        const uint32_t blocks5 = (uint32_t)std::max<uint64_t>(
+            1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
+        tgx::Encode5Params q{};
+        q.trie8 = m->d_trie8;
+        q.cold_scores = m->d_cold_scores;
+        q.hot = m->d_hot;
+        q.root_base = m->root_base8;
+        q.n_hot = m->n_hot;
+        q.pool_entries = kE5PoolEntries;
+        q.redo_count = m->d_ctrl + 6;
+        q.redo_list = c->d_counts;  // free until the trace writes the token counts
+        m->last_redo_samples = 0;
+        if (m->has_cold) HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
+        unsigned long long* d_stamps5 = nullptr;
+        const size_t n_stamp_waves5 = (size_t)blocks5 * (size_t)waves;
+        if (const char* e = getenv("TGX_STAMPS")) {
+            if (*e == '1') {
+                HIP_TRY(hipMalloc((void**)&d_stamps5, n_stamp_waves5 * 64));
+                HIP_TRY(hipMemsetAsync(d_stamps5, 0, n_stamp_waves5 * 64, m->stream));
+                p.stamps = d_stamps5;
+            }
+        }
+        time_begin(m, "encode5_kernel");
+        HIP_TRY(tgx::launch_encode5(p, q, m->has_cold, ppl, waves, blocks5, m->stream));
+        time_end(m);
+        if (d_stamps5) {  // diagnostic: mean ticks per iteration and phase over all waves
+            std::vector<unsigned long long> h(n_stamp_waves5 * 8);
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            HIP_TRY(hipMemcpy(h.data(), d_stamps5, n_stamp_waves5 * 64, hipMemcpyDeviceToHost));
+            double sum[5] = {0, 0, 0, 0, 0}, iters = 0;
+            for (size_t w = 0; w < n_stamp_waves5; w++) {
+                for (int i = 0; i < 5; i++) sum[i] += (double)h[w * 8 + i];
+                iters += (double)h[w * 8 + 5];
+            }
+            fprintf(stderr, "[tgx] encode5 stamps (s_memtime ticks per wave-iteration, %zu waves x ppl %d, %.0f iterations): switch %.0f  text+reset %.0f  walk %.0f  relax %.0f  store %.0f\n",
+                    n_stamp_waves5, ppl, iters, sum[0] / iters, sum[1] / iters, sum[2] / iters, sum[3] / iters, sum[4] / iters);
+            (void)hipFree(d_stamps5);
+            p.stamps = nullptr;
+        }
+        if (m->has_cold) {  // only a vocabulary with values outside the table can run a wave out of pool entries
+            unsigned long long n_redo = 0;
+            HIP_TRY(hipMemcpyAsync(&n_redo, m->d_ctrl + 6, 8, hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (n_redo > c->n_samples) return fail(TGX_ERR_DEVICE, "redo list longer than the batch");
+            m->last_redo_samples = n_redo;
+            if (n_redo) {
+                tgx::EncodeParams r4 = p;
+                r4.order = c->d_counts;
+                r4.n_samples = n_redo;
+                HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
+                const uint32_t b4 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_redo + 39) / 40, (uint64_t)m->num_cus * 2));
+                time_begin(m, "encode4_kernel");
+                HIP_TRY(tgx::launch_encode4(r4, 1, 10, b4, true, m->stream));
+                time_end(m);
+            }
+        }
+        const uint32_t blocks_t =
+            (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
+        time_begin(m, "trace_kernel");
+        HIP_TRY(tgx::launch_trace(p, blocks_t, m->stream));
+        time_end(m);
+    } else if (use4) {
         // `bpc` blocks per CU of `waves` waves each (8 KiB of LDS per wave and position group).
         // TGX_PPL (positions per lane: 1, 2, 4), TGX_WAVES, TGX_BPC override the defaults.
         // Two blocks of ten waves per CU (20 x 8 KiB of LDS); rows claim samples dynamically, so the
@@ -562,6 +677,32 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
             HIP_TRY_M(hipMemcpyAsync(m->d_tokhash, m->tokhash.slots.data(), hb, hipMemcpyHostToDevice, m->stream));
         }
     }
+    if (m->lm <= 16 && m->scores_finite && m->d_tokhash && m->flat.table.size() < (1u << 23)) {
+        tgx::Trie8 t8;
+        uint32_t max_hot = kE5MaxHot;
+        if (const char* e = getenv("TGX_E5_MAX_HOT")) {  // tests: a small table forces the cold-value paths
+            const int v = atoi(e);
+            if (v >= 0 && v <= (int)kE5MaxHot) max_hot = (uint32_t)v;
+        }
+        tgx::build_trie8(m->flat, vocab_size ? offs : zero_offs, scores, max_hot, &t8);
+        const size_t ns = t8.rec.size();
+        HIP_TRY_M(hipMalloc(&m->d_trie8, ns * sizeof(tgx::Trie8Rec)));
+        HIP_TRY_M(hipMalloc((void**)&m->d_cold_scores, ns * 8));
+        HIP_TRY_M(hipMalloc((void**)&m->d_hot, std::max<size_t>(8, t8.hot.size() * 8)));
+        HIP_TRY_M(hipMemcpy(m->d_trie8, t8.rec.data(), ns * sizeof(tgx::Trie8Rec), hipMemcpyHostToDevice));
+        HIP_TRY_M(hipMemcpy(m->d_cold_scores, t8.cold_scores.data(), ns * 8, hipMemcpyHostToDevice));
+        if (!t8.hot.empty()) HIP_TRY_M(hipMemcpy(m->d_hot, t8.hot.data(), t8.hot.size() * 8, hipMemcpyHostToDevice));
+        m->n_hot = (uint32_t)t8.hot.size();
+        m->root_base8 = t8.root_base;
+        m->hot_coverage = t8.hot_coverage;
+        m->has_cold = false;
+        for (const tgx::Trie8Rec& q : t8.rec)
+            if (q.sref & tgx::kTrie8Cold) {
+                m->has_cold = true;
+                break;
+            }
+        m->have_trie8 = true;
+    }
     HIP_TRY_M(hipHostMalloc((void**)&m->h_ctrl, 64, hipHostMallocDefault));
     HIP_TRY_M(hipMemcpyAsync(m->d_trie, m->flat.table.data(), tbytes, hipMemcpyHostToDevice, m->stream));
     HIP_TRY_M(hipMemcpyAsync(m->d_tokid, m->flat.tokid.data(), m->flat.tokid.size() * 4,
@@ -596,6 +737,9 @@ void tgx_model_destroy(tgx_model* m) {
     if (m->d_trie_w) (void)hipFree(m->d_trie_w);
     if (m->d_trie_rev_w) (void)hipFree(m->d_trie_rev_w);
     if (m->d_tokhash) (void)hipFree(m->d_tokhash);
+    if (m->d_trie8) (void)hipFree(m->d_trie8);
+    if (m->d_cold_scores) (void)hipFree(m->d_cold_scores);
+    if (m->d_hot) (void)hipFree(m->d_hot);
     if (m->d_tokid) (void)hipFree(m->d_tokid);
     if (m->d_ctrl) (void)hipFree(m->d_ctrl);
     if (m->h_ctrl) (void)hipHostFree(m->h_ctrl);
@@ -619,9 +763,6 @@ tgx_status tgx_common_prefix_search(const tgx_model* m, const uint8_t* s, uint64
 
 // ---- host-only trie introspection ----------------------------------------------
 
-struct tgx_flat_trie {  // also defined in prune_host.cpp (same layout)
-    tgx::FlatTrie flat;
-};
 
 tgx_status tgx_flat_trie_build(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                                uint32_t vocab_size, tgx_flat_trie** out) {
@@ -636,6 +777,29 @@ void tgx_flat_trie_free(tgx_flat_trie* t) { delete t; }
 uint64_t tgx_flat_trie_search(const tgx_flat_trie* t, const uint8_t* s, uint64_t n, uint32_t* ids,
                               uint32_t* lens, uint64_t cap) {
     return t ? tgx::flat_common_prefix_search(t->flat, s, n, ids, lens, cap) : 0;
+}
+uint64_t tgx_flat_trie_search8(const tgx_flat_trie* t, const uint8_t* bytes, const uint64_t* offs, const double* scores,
+                               uint32_t max_hot, const uint8_t* s, uint64_t n, uint32_t* ids, uint32_t* lens,
+                               uint64_t cap, uint32_t* n_hot, uint64_t* n_cold, double* hot_coverage) {
+    if (!t || t->flat.table.size() >= (1u << 23)) return ~0ULL;
+    static const uint64_t zero_offs[1] = {0};
+    // (test infrastructure: the records of the last max_hot asked for are kept on the handle)
+    tgx_flat_trie* tm = const_cast<tgx_flat_trie*>(t);
+    if (!tm->t8 || tm->t8_max_hot != max_hot) {
+        tm->t8.reset(new tgx::Trie8());
+        tgx::build_trie8(t->flat, offs ? offs : zero_offs, scores, max_hot, tm->t8.get());
+        tm->t8_max_hot = max_hot;
+    }
+    const tgx::Trie8& t8 = *tm->t8;
+    (void)bytes;
+    if (n_hot) *n_hot = (uint32_t)t8.hot.size();
+    if (n_cold) {
+        uint64_t k = 0;
+        for (const tgx::Trie8Rec& q : t8.rec) k += (q.sref & tgx::kTrie8Cold) ? 1 : 0;
+        *n_cold = k;
+    }
+    if (hot_coverage) *hot_coverage = t8.hot_coverage;
+    return tgx::trie8_common_prefix_search(t8, t->flat, s, n, ids, lens, cap);
 }
 void tgx_flat_trie_stats(const tgx_flat_trie* t, uint64_t* n_slots, uint64_t* n_nodes,
                          uint32_t* max_token_len) {

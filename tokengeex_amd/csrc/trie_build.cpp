@@ -17,6 +17,7 @@ struct Edge {
 
 struct BlockAlloc {
     std::vector<uint64_t> used;      // 4 words per 256-slot block
+    std::vector<uint64_t> base_used; // 4 words per block: bit x = some node's children live at (block << 8 | x) ^ byte
     std::vector<uint16_t> free_cnt;  // per block
     uint32_t head1 = 0;              // first block that may have a free slot
     uint32_t headk = 0;              // first block worth trying for multi-child nodes
@@ -24,6 +25,9 @@ struct BlockAlloc {
     uint32_t n_blocks() const { return (uint32_t)free_cnt.size(); }
     void add_block() {
         used.insert(used.end(), 4, 0ULL);
+        // low bytes 0xFE and 0xFF are never the base of a node with children: the label-checked 8-byte
+        // records (build_trie8) point leaves at 0xFE and give unused slot t the label (t ^ 0xFF) & 0xFF
+        base_used.insert(base_used.end(), {0ULL, 0ULL, 0ULL, 3ULL << 62});
         free_cnt.push_back(256);
     }
     bool is_used(uint32_t t) const { return (used[t >> 6] >> (t & 63)) & 1ULL; }
@@ -128,6 +132,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     BlockAlloc ba;
     ba.add_block();
     ba.mark(0);  // root
+    ba.free_cnt[0] = 0;  // block 0 holds the root only: leaves of the 8-byte records point into it (base 0xFE)
     std::vector<uint32_t> slot(n_nodes, 0), base(n_nodes, 0);
     // Expansion order: descending weight, the older node first among equals.  A parent weighs at least as
     // much as any of its children and was created before them, so one sort gives an order in which every
@@ -151,12 +156,30 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
         uint32_t chosen = 0;
         bool found = false;
         if (k == 1) {
+            // lowest free slot f of the first block that has one whose base f ^ byte is still unclaimed (bases are
+            // unique, so that a record can be checked by its edge byte alone: build_trie8)
             while (ba.head1 < ba.n_blocks() && ba.free_cnt[ba.head1] == 0) ba.head1++;
-            if (ba.head1 == ba.n_blocks()) ba.add_block();
-            uint32_t b = ba.head1;
-            int f = ba.first_free_in_block(b);
-            chosen = (b << 8) | ((uint32_t)f ^ edges[lo].byte);
-            found = true;
+            const uint32_t c = edges[lo].byte;
+            for (uint32_t b = ba.head1; !found; b++) {
+                if (b == ba.n_blocks()) ba.add_block();
+                if (ba.free_cnt[b] == 0) continue;
+                for (uint32_t w = 0; w < 4 && !found; w++) {
+                    // slot f = x ^ c is free and base x is unclaimed: permute the claimed-base mask like the slots below
+                    uint64_t bu = ba.base_used[(size_t)b * 4 + (w ^ (c >> 6))];
+                    if (c & 1u) bu = ((bu >> 1) & 0x5555555555555555ULL) | ((bu & 0x5555555555555555ULL) << 1);
+                    if (c & 2u) bu = ((bu >> 2) & 0x3333333333333333ULL) | ((bu & 0x3333333333333333ULL) << 2);
+                    if (c & 4u) bu = ((bu >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((bu & 0x0F0F0F0F0F0F0F0FULL) << 4);
+                    if (c & 8u) bu = ((bu >> 8) & 0x00FF00FF00FF00FFULL) | ((bu & 0x00FF00FF00FF00FFULL) << 8);
+                    if (c & 16u) bu = ((bu >> 16) & 0x0000FFFF0000FFFFULL) | ((bu & 0x0000FFFF0000FFFFULL) << 16);
+                    if (c & 32u) bu = (bu >> 32) | (bu << 32);
+                    const uint64_t ok = ~ba.used[(size_t)b * 4 + w] & ~bu;  // bit f: slot f free and base f ^ c unclaimed
+                    if (ok) {
+                        const uint32_t f = w * 64u + (uint32_t)__builtin_ctzll(ok);
+                        chosen = (b << 8) | (f ^ c);
+                        found = true;
+                    }
+                }
+            }
         } else {
             while (ba.headk < ba.n_blocks() && ba.free_cnt[ba.headk] < 24) ba.headk++;
             uint32_t tried = 0;
@@ -166,7 +189,8 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
                 // x fits iff used[x ^ c] is clear for every child byte c: OR the block's mask permuted by each
                 // c (bit x of the permuted mask = bit x ^ c of the mask) and take the lowest clear bit
                 const uint64_t* u = &ba.used[(size_t)b * 4];
-                uint64_t forbidden[4] = {0, 0, 0, 0};
+                const uint64_t* bu = &ba.base_used[(size_t)b * 4];
+                uint64_t forbidden[4] = {bu[0], bu[1], bu[2], bu[3]};  // bases are unique (build_trie8)
                 for (uint32_t j = lo; j < hi; j++) {
                     const uint32_t c = edges[j].byte;
                     for (uint32_t w = 0; w < 4; w++) {
@@ -193,10 +217,15 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
             }
         }
         base[node] = chosen;
+        ba.base_used[chosen >> 6] |= 1ULL << (chosen & 63u);
         for (uint32_t j = lo; j < hi; j++) {
             uint32_t t = chosen ^ edges[j].byte;
             ba.mark(t);
             slot[edges[j].child] = t;
+        }
+        {   // a block whose 256 base values are all claimed (or reserved) can take no further sibling set
+            const uint64_t* bu = &ba.base_used[(size_t)(chosen >> 8) * 4];
+            if ((bu[0] & bu[1] & bu[2] & bu[3]) == ~0ULL) ba.free_cnt[chosen >> 8] = 0;
         }
     }
 
@@ -204,9 +233,14 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     uint32_t n_slots = ba.n_blocks() * 256;
     out->table.assign(n_slots, TrieRec{kNoParent, 0, 0});
     out->tokid.assign(n_slots, kNoToken);
+    out->label.assign(n_slots, 0);
+    out->inner.assign(n_slots, 0);
     out->table[0].base = base[0];
+    out->inner[0] = row[1] > row[0];
     for (const Edge& e : edges) {
         uint32_t t = slot[e.child];
+        out->label[t] = e.byte;
+        out->inner[t] = row[e.child + 1] > row[e.child];
         TrieRec& r = out->table[t];
         r.check = slot[e.parent];
         r.base = base[e.child];
@@ -219,6 +253,98 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     }
     out->max_token_len = max_len;
     out->n_nodes = n_nodes;
+}
+
+// ---- 8-byte label-checked records + score table (encode5_kernel) ----------------------------------------
+void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, uint32_t max_hot, Trie8* out) {
+    const uint32_t n_slots = (uint32_t)ft.table.size();
+    out->rec.assign(n_slots, Trie8Rec{0, 0});
+    out->cold_scores.assign(n_slots, 0.0);
+    out->hot.clear();
+    out->hot_coverage = 1.0;
+    // distinct score values (by bit pattern) of the tokens that can match, weighted by how often their
+    // tokens are expected to match: a token of probability mass w and length l starts at about w / l of
+    // the positions (its Viterbi share; the proxy only has to rank the values)
+    struct Val {
+        uint64_t bits;
+        double weight;
+        uint32_t first_slot;
+    };
+    std::vector<std::pair<uint64_t, uint32_t>> by_bits;  // (score bits, slot) of terminal slots
+    by_bits.reserve(n_slots / 2);
+    for (uint32_t t = 0; t < n_slots; t++)
+        if (ft.tokid[t] != kNoToken) by_bits.push_back({ft.table[t].score_bits, t});
+    std::sort(by_bits.begin(), by_bits.end());
+    std::vector<Val> vals;
+    std::vector<uint32_t> val_of(by_bits.size());  // by_bits index -> vals index
+    double total_w = 0.0;
+    for (size_t i = 0; i < by_bits.size(); i++) {
+        if (i == 0 || by_bits[i].first != by_bits[i - 1].first) vals.push_back(Val{by_bits[i].first, 0.0, by_bits[i].second});
+        const uint32_t id = ft.tokid[by_bits[i].second];
+        const double len = (double)std::max<uint64_t>(1, offs[id + 1] - offs[id]);
+        double w = std::exp(scores[id]) / len;
+        if (!(w == w) || w > 1e300) w = 0.0;
+        vals.back().weight += w;
+        total_w += w;
+        val_of[i] = (uint32_t)vals.size() - 1;
+    }
+    std::vector<uint32_t> order(vals.size());
+    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if (vals[a].weight != vals[b].weight) return vals[a].weight > vals[b].weight;
+        return vals[a].bits < vals[b].bits;
+    });
+    const uint32_t n_hot = (uint32_t)std::min<size_t>(order.size(), max_hot);
+    std::vector<uint32_t> rank(vals.size(), 0xFFFFFFFFu);
+    double hot_w = 0.0;
+    out->hot.resize(n_hot);
+    for (uint32_t r = 0; r < n_hot; r++) {
+        rank[order[r]] = r;
+        out->hot[r] = vals[order[r]].bits;
+        hot_w += vals[order[r]].weight;
+    }
+    if (total_w > 0.0 && n_hot < order.size()) out->hot_coverage = std::min(hot_w / total_w, 1.0 - 1e-12);
+    std::vector<uint32_t> sref(n_slots, 0);
+    for (size_t i = 0; i < by_bits.size(); i++) {
+        const uint32_t t = by_bits[i].second, r = rank[val_of[i]];
+        // hot: byte offset of the value in the kernel's LDS score region (entry 0 is -inf); cold: the slot
+        sref[t] = kTrie8Terminal | (r != 0xFFFFFFFFu ? 8u * (r + 1u) : (kTrie8Cold | t));
+        std::memcpy(&out->cold_scores[t], &by_bits[i].first, 8);
+    }
+    for (uint32_t t = 0; t < n_slots; t++) {
+        Trie8Rec& q = out->rec[t];
+        const bool used = t != 0 && ft.table[t].check != kNoParent;
+        if (used) {
+            const uint32_t base = ft.inner[t] ? (ft.table[t].base & ~kTerminalBit) : kTrie8LeafBase;
+            q.rec = (uint32_t)ft.label[t] | (base << 8);
+            q.sref = sref[t];
+        } else {  // unused slots (and the root's own slot) can never pass the label check: see BlockAlloc::add_block
+            q.rec = ((t ^ 0xFFu) & 0xFFu) | (kTrie8LeafBase << 8);
+            q.sref = 0;
+        }
+    }
+    out->root_base = ft.inner[0] ? (ft.table[0].base & ~kTerminalBit) : kTrie8LeafBase;
+}
+
+uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const uint8_t* s, uint64_t n, uint32_t* ids,
+                                    uint32_t* lens, uint64_t cap) {
+    uint32_t base = t8.root_base;
+    uint64_t found = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t t = base ^ s[i];
+        if (t >= t8.rec.size()) break;
+        const uint32_t r = t8.rec[t].rec;
+        if ((r & 0xFFu) != s[i]) break;
+        base = r >> 8;
+        if (t8.rec[t].sref & kTrie8Terminal) {
+            if (found < cap) {
+                ids[found] = ft.tokid[t];
+                lens[found] = (uint32_t)(i + 1);
+            }
+            found++;
+        }
+    }
+    return found;
 }
 
 static bool fill_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out) {

@@ -13,6 +13,7 @@
 // terminal slot (read once per emitted token, not per match).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 namespace tgx {
@@ -31,6 +32,8 @@ constexpr uint32_t kNoToken = 0xFFFFFFFFu;
 struct FlatTrie {
     std::vector<TrieRec> table;   // n_slots records (multiple of 256)
     std::vector<uint32_t> tokid;  // n_slots, kNoToken when not terminal
+    std::vector<uint8_t> label;   // n_slots: byte of the edge that leads to the slot (used slots other than the root)
+    std::vector<uint8_t> inner;   // n_slots: the node has children
     uint32_t max_token_len = 0;
     uint32_t n_nodes = 0;
 };
@@ -40,6 +43,34 @@ struct FlatTrie {
 // stored on the root and can never match (src/trie.rs:53-61), so they are skipped.
 void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                      uint32_t vocab_size, FlatTrie* out);
+
+// Label-checked 8-byte records over the SAME slot assignment (encode5_kernel): the walk keeps only `base`,
+//   t = base ^ byte;  {rec, sref} = table[t];  valid iff (rec & 0xFF) == byte;  base = rec >> 8;  terminal = sref bit 31
+// which is exact because build_flat_trie gives every node with children a base of its own (if slot t passes
+// the check for (base, byte) its owner's base is t ^ byte = base) whose low byte is neither 0xFE nor 0xFF:
+// leaves point at base 0xFE of block 0 (the root's block, otherwise empty) and an unused slot t carries the
+// label (t ^ 0xFF) & 0xFF, so neither can pass.  `sref` of a terminal slot says where its score is: the byte
+// offset (below 64 KiB) of its VALUE in the kernel's LDS score table (distinct score values, the ones expected to match most
+// often first; entry 0 of the table is -inf), or kTrie8Cold | slot when the value did not make the table
+// (cold_scores[slot] in HBM).  generate-style vocabularies score tokens by integer counts and have a few
+// thousand distinct values; after an M-step every token has its own.
+struct Trie8Rec {
+    uint32_t rec;   // label | base << 8
+    uint32_t sref;  // 0 for a slot no token ends at; else kTrie8Terminal | (LDS byte offset, or kTrie8Cold | slot)
+};
+constexpr uint32_t kTrie8Terminal = 0x80000000u;
+constexpr uint32_t kTrie8Cold = 0x40000000u;
+constexpr uint32_t kTrie8LeafBase = 0xFEu;
+struct Trie8 {
+    std::vector<Trie8Rec> rec;        // n_slots
+    std::vector<double> cold_scores;  // n_slots: score of every terminal slot
+    std::vector<uint64_t> hot;        // bit patterns of the LDS table's values, entry i at byte offset 8 (i + 1)
+    uint32_t root_base = 0;
+    double hot_coverage = 1.0;        // expected share of the matches whose score is in the table
+};
+void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, uint32_t max_hot, Trie8* out);
+uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const uint8_t* s, uint64_t n, uint32_t* ids,
+                                    uint32_t* lens, uint64_t cap);
 
 // Token-bytes -> id hash table (tokens of 1..32 bytes): lets the trace kernel turn a
 // (start, length) pair straight into a token id with one probe instead of carrying a trie
@@ -105,3 +136,10 @@ uint64_t flat_common_prefix_search(const FlatTrie& t, const uint8_t* s, uint64_t
                                    uint32_t* lens, uint64_t cap);
 
 }  // namespace tgx
+
+// host-only handle of include/tgx.h's tgx_flat_trie_* functions (tgx_api.cpp, prune_host.cpp)
+struct tgx_flat_trie {
+    tgx::FlatTrie flat;
+    std::unique_ptr<tgx::Trie8> t8;  // tgx_flat_trie_search8: records of the last max_hot asked for
+    uint32_t t8_max_hot = 0;
+};
