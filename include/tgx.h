@@ -185,6 +185,11 @@ tgx_status tgx_estep(tgx_model *m, tgx_corpus *c, uint64_t snippet_len, double d
                      uint64_t seed, double *expected, double *logz_sum);
 
 void tgx_free(void *p);
+/* Scratch and result buffers are recycled through a per-process pool of device buffers (at most a quarter of
+ * the device's memory; flushed and retried automatically when an allocation fails).  tgx_pool_trim returns every
+ * pooled buffer of `device` (all devices if negative) to the HIP runtime, e.g. before another library needs
+ * the memory. */
+void tgx_pool_trim(int device);
 
 /* ---- prune host logic (no device needed) ---------------------
  * The O(V) steps of ModelVocabularyPruner between the corpus passes above. */

@@ -1,0 +1,123 @@
+"""BASELINE.json's configurations that the other GPU tests do not run at their own parameters:
+
+  configs[0]  encode_batch on 10 MB of synthetic ASCII with the 32 000-entry vocabulary — the whole batch against
+              the CPU oracle (reference src/tokenizer.rs:102-123 over src/model.rs:59-129);
+  configs[3]  the prune passes at the 500 000-entry vocabulary (E-step src/prune.rs:64-120, frequency pass
+              src/prune.rs:205-244) — a bounded prefix of the corpus against the oracle;
+  the driver's multi-GPU command: `python bench.py --gpus N` starts its own ranks (two of them here, both on
+  the one GPU of the test box).
+"""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import tokengeex_amd as tgx
+from oracle import oracle as orc
+from tokengeex_amd import synth
+
+from util import assert_same_encoding, load_vocab_500k
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_config0_10mb_ascii_32k_vocab():
+    vflat, _ = synth.make_corpus(4 << 20, "ascii", seed_offset=0)
+    toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
+    assert len(toks) == 32000
+    flat, offs = synth.make_corpus(10_000_000, "ascii", seed_offset=1000)
+    assert abs(int(flat.size) - 10_000_000) < 70_000 and int(flat.max()) < 128
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    ids, oo = assert_same_encoding(nat, ora, flat, offs)
+    assert "encode5_kernel" in nat.last_kernel_times()
+    # and sample by sample through the reference's single-threaded path (configs[0]: "single thread")
+    want_ids, want_oo = ora.encode_batch_flat(flat, offs, threads=1)
+    np.testing.assert_array_equal(ids, want_ids)
+    np.testing.assert_array_equal(oo, want_oo)
+    freq = nat.count_tokens(tgx.NativeCorpus(flat, offs))
+    np.testing.assert_array_equal(freq, np.bincount(want_ids, minlength=len(toks)).astype(np.uint64))
+
+
+def test_config3_prune_passes_at_500k_vocab():
+    toks, scores = load_vocab_500k()
+    flat, offs = synth.make_corpus(24 << 20, "mixed", seed_offset=1000)
+    k = int(np.searchsorted(offs, 6 << 20))          # ~6 MiB: seconds of oracle time at this vocabulary
+    sf, so = flat[: int(offs[k])], offs[: k + 1]
+    nat, ora = tgx.NativeModel(toks, scores, for_estep=True), orc.OracleModel(toks, scores)
+    assert nat.vocab_size == 500000
+    # encode + frequency pass: bit-exact
+    ids, _ = assert_same_encoding(nat, ora, sf, so)
+    corpus = tgx.NativeCorpus(sf, so)
+    freq = nat.count_tokens(corpus)
+    np.testing.assert_array_equal(freq, ora.count_tokens_flat(sf, so, threads=8))
+    np.testing.assert_array_equal(freq, np.bincount(ids, minlength=len(toks)).astype(np.uint64))
+    # E-step: expected counts to the documented tolerance (tests/test_estep_pairs_gpu.py), same support, same z
+    got, gz = nat.estep(corpus)
+    st, want, wz, _ = ora.estep_flat(sf, so, threads=8)
+    assert st == orc.OK
+    longest = int(np.diff(so.astype(np.int64)).max())
+    np.testing.assert_allclose(got, want, rtol=1.2e-8 * max(1.0, longest / 4096.0), atol=1e-12)
+    assert np.array_equal(got != 0, want != 0)
+    assert abs(gz - wz) <= 1e-12 * abs(wz) + 1e-9
+    mass = float(np.dot(got, np.array([len(t) for t in toks], np.float64)))
+    assert abs(mass - sf.size) < 1e-6 * sf.size       # every byte covered with total mass 1
+    assert any(name.startswith("estep4l") for name in nat.last_kernel_times())
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent launches two ranks before it touches the
+    GPU and rank 0 prints the one line with n_gpus = 2 (whole-job throughput, a CPU-port leg on rank 0)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device", "--size-mb", "64",
+                        "--steps", "3", "--warmup", "1", "--cpu-seconds", "2", "--master-port", "29547"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["bytes_per_gpu"] >= 60 << 20 and out["value"] > 0
+    assert out["roofline"]["achieved"] > 0 and out["cpu_baseline"]["cores"] >= 1 and out["cpu_baseline"]["value_1thread"] > 0
+
+
+def test_two_models_share_one_resident_corpus_from_two_threads():
+    """prune and merge keep the corpus in HBM while models come and go (src/prune.rs:48); two models encoding
+    and scanning the SAME corpus handle from two host threads must not see each other's scratch."""
+    flat, offs = synth.make_corpus(6 << 20, "mixed", seed_offset=21, max_len=20000)
+    toks, scores = synth.build_vocab(flat[: 2 << 20], 6000, 16)
+    toks2 = toks[:2500] + [bytes([b]) for b in range(255) if bytes([b]) not in set(toks[:2500])]
+    scores2 = np.concatenate([np.asarray(scores[:2500]) * 1.03, np.full(len(toks2) - 2500, -11.0)])
+    models = [(tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)),
+              (tgx.NativeModel(toks2, scores2), orc.OracleModel(toks2, scores2))]
+    want = [(o.encode_batch_flat(flat, offs, threads=8), o.count_tokens_flat(flat, offs, threads=8)) for _, o in models]
+    corpus = tgx.NativeCorpus(flat, offs)
+    got, errors = [None, None], []
+
+    def work(i):
+        try:
+            out = []
+            for _ in range(6):
+                res = models[i][0].encode_corpus(corpus)
+                out.append((res.ids().copy(), res.offsets().copy(), models[i][0].count_tokens(corpus)))
+                res.free()
+            got[i] = out
+        except Exception as e:  # surfaced in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for ids, oo, freq in got[i]:
+            np.testing.assert_array_equal(ids, want[i][0][0])
+            np.testing.assert_array_equal(oo, want[i][0][1])
+            np.testing.assert_array_equal(freq, want[i][1])

@@ -213,19 +213,23 @@ def test_non_finite_scores_use_the_exact_generic_path():
         assert "encode4_kernel" not in nat.last_kernel_times()
 
 
-@pytest.mark.parametrize("path,kernel,min_waves", [("rows5", "encode5_kernel", 24), ("rows4", "encode4_kernel", 18)])
+@pytest.mark.parametrize("path,kernel,min_waves", [("rows5", "encode5_kernel", 28), ("rows4", "encode4_kernel", 18)])
 def test_launch_geometry_fits_the_device(monkeypatch, path, kernel, min_waves):
     """The four-samples-per-wave kernels must really have their planned waves resident: two blocks of nine or
     ten waves put six waves on some SIMD, which needs encode4_kernel to stay within 80 VGPRs (a build that
     drifted to 82 ran at half occupancy, 28 ms instead of 18 ms per GiB, without failing any parity test)."""
-    flat, offs, toks, scores = corpus_and_vocab(8 << 20, "mixed", 4000, 16, max_len=2048)
+    flat, offs, toks, scores = corpus_and_vocab(16 << 20, "mixed", 4000, 16, max_len=256)   # more samples than the chip has rows
     nat = tgx.NativeModel(toks, scores)
-    monkeypatch.setenv("TGX_PPL", "1")       # one position per lane: the bench's variant, whatever the corpus shape
+    monkeypatch.setenv("TGX_PPL", "1")       # one position per lane: the variant with the most waves per CU
     monkeypatch.setenv("TGX_PATH", path)
     res = nat.encode_batch_flat(flat, offs)
     res.free()
     assert kernel in nat.last_kernel_times()
     assert nat.last_encode_waves_per_cu() >= min_waves
+    if path == "rows5":   # the default: four positions per lane, one block of sixteen waves per CU
+        monkeypatch.delenv("TGX_PPL")
+        nat.encode_batch_flat(flat, offs).free()
+        assert nat.last_encode_waves_per_cu() == 16
 
 
 @pytest.mark.parametrize("path", ["rows5", "rows4"])

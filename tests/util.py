@@ -81,3 +81,18 @@ def estep_longdouble(oracle_model, text: bytes):
             else:
                 bm[p] = bm[p] + np.ldexp(term, be[q] - be[p])
     return expected.astype(np.float64), logz
+
+
+def load_vocab_500k():
+    """The 500 000-entry synthetic vocabulary of BASELINE.json configs[3] (prune's start): built once by
+    tools/make_vocab_cache.py 500000 (synth.build_vocab over 64 MiB of the mixed corpus, minutes of numpy) and
+    committed, compressed, as tests/golden/vocab_500000.npz (token bytes, lengths, distinct score values + index).
+    -> (tokens: list[bytes], scores: float64[500000])"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vocab_500000.npz"))
+    fb = z["flat"].tobytes()
+    o = np.concatenate([[0], np.cumsum(z["lens"].astype(np.int64))])
+    toks = [fb[o[i]:o[i + 1]] for i in range(o.size - 1)]
+    scores = z["uscores"][z["inv"]].astype(np.float64)
+    assert len(toks) == 500000 and scores.size == 500000
+    return toks, scores

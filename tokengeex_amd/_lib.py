@@ -65,6 +65,7 @@ SYMBOLS = {
     "tgx_count_pairs_top": (_i, [_vp, _vp, _u64, _pvp, _pvp, _pu64, _pu64]),
     "tgx_estep": (_i, [_vp, _vp, _u64, _d, _u64, _vp, C.POINTER(C.c_double)]),
     "tgx_free": (None, [_vp]),
+    "tgx_pool_trim": (None, [_i]),
     "tgx_digamma": (_d, [_d]),
     "tgx_prune_m_step": (_i, [_vp, _vp, _u32, _vp, _vp, C.POINTER(C.c_uint32)]),
     "tgx_prune_alternatives": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _pvp]),
@@ -113,6 +114,11 @@ def check(status: int) -> None:
         lib.tgx_last_error_detail(C.byref(s), C.byref(p), C.byref(l))
         raise TokenGeeXError(msg, status, s.value, p.value, l.value)
     raise TokenGeeXError(msg, status)
+
+
+def pool_trim(device: int = -1) -> None:
+    """Returns the library's pooled device buffers to the HIP runtime (all devices if negative)."""
+    lib.tgx_pool_trim(device)
 
 
 def device_count() -> int:

@@ -25,16 +25,15 @@
 
 namespace tgx {
 
-// match-index buffer of one 16-position group: four sample rows of 32 columns x 16 start positions x 2 bytes,
-// row stride 1040 bytes (the 16 extra bytes spread the ds_read_b128 of a lane group over all banks).
-// Entry (start u, len) of row r: r * 1040 + (u + len - 1) * 32 + u * 2, so a walker lane's address is a
-// per-lane constant plus (len - 1) * 32 — an instruction offset, no address arithmetic in the walk.  Lane l of
-// the row, which at step u accumulates end position u + len with len - 1 = (l - u - 1) & 15, finds its entries
-// in column l - 1 (steps u < l) and column l + 15 (steps u >= l); the rows of either column that belong to
-// the other are never written, so OR-ing the two 32-byte columns gives the lane's 16 entries.  Lane 0 reads
-// column 31, which nothing writes.
-constexpr uint32_t kE5RowStride = 1040;
-constexpr uint32_t kE5GroupBytes = 4 * kE5RowStride;  // 4160
+// match-index buffer of one 16-position group: four sample rows of 16 columns x 16 start positions x 2 bytes
+// = 2 KiB per wave and group, 512-byte aligned.  Entry (start u, len) of row r: r * 512 + ((len - 1 + u) & 15) * 32
+// + u * 2 — lane l of the row, which at step u accumulates end position u + len with len - 1 = (l - u - 1) & 15,
+// finds its 16 entries (u = 0..15) contiguous in column (l - 1) & 15: two ds_read_b128.  The walker's address is
+// (lane constant) | ((l * 32 + d * 32) & 0x1E0): the alignment makes it one add and one and-or.  (A layout with
+// 32 columns and no wrap-around needs no address arithmetic at all but twice the LDS, and LDS is what limits the
+// waves per CU here.)
+constexpr uint32_t kE5RowStride = 512;
+constexpr uint32_t kE5GroupBytes = 4 * kE5RowStride;  // 2048
 
 // sref of a record (trie_build.h: Trie8Rec): bit 31 terminal, bit 30 cold, low bits LDS byte offset / slot
 constexpr uint32_t kSrefCold = 0x40000000u;
@@ -45,55 +44,44 @@ struct WalkCtx {
     const uint2* rootc;
     unsigned char* smem;
     const double* __restrict__ cold_scores;
-    uint32_t root_base, pool_entries, pool_off, s, flags;
+    uint32_t root_base, pool_entries, pool_off, s, flags, l32;
     double dropout;
     uint64_t seed;
 };
 
-// ---- one trie step of all PPL walks of a lane, depth D a compile-time constant (the loop over depths is
-// unrolled by template recursion: with its early exit and the wave-wide pool allocation inside, hipcc's
-// unroller gives up on the plain loop and the text bytes end up selected by v_cndmask chains).
+// ---- the trie walks of a lane (PPL start positions), unrolled over the depth D by template recursion (with
+// its early exit and the wave-wide pool allocation inside, hipcc's unroller gives up on the plain loop and the
+// text bytes end up selected by v_cndmask chains).  The PPL walks are STAGGERED: a level consumes the record of
+// walk g and at once requests walk g's next record, so while one walk's record is examined (about 25
+// instructions) the gathers of the other walks are in flight (vector loads return in order: the wait for walk g's
+// record leaves the PPL - 1 younger ones outstanding).  With all gathers of a depth issued together and waited
+// for together a step of two walks took 890 cycles against 540 for one.
 // COLD = false is the build for vocabularies whose score values all fit the LDS table: no pool code at all.
+// (Every lane issues every gather, finished walks from slot 0: a load that only some paths issue would force
+// the compiler to wait for ALL outstanding loads at every use — in-order counters cannot name a load that may
+// not exist — and the stagger would be lost.  For the same reason the hottest slots are NOT read from an LDS
+// copy: tried, 2 % at best, a step still waits for its slowest lane, which goes to L2.)
+
 template <bool DROPOUT, bool COLD, int PPL, int D>
 struct Walk5 {
+    // rec[g], c[g]: record and text byte of depth D of walk g (the load may still be in flight)
     static __device__ __forceinline__ void run(const WalkCtx<PPL>& W, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
-                                               const uint32_t (&pg)[PPL], unsigned char* const (&wlane)[PPL], bool (&alive)[PPL],
-                                               uint32_t (&base)[PPL], double (&pend_val)[PPL], uint32_t (&pend_addr)[PPL],
-                                               uint32_t& pool_cnt, bool& bad) {
+                                               const uint32_t (&pg)[PPL], const uint32_t (&wlane)[PPL], bool (&alive)[PPL],
+                                               uint2 (&rec)[PPL], uint32_t (&c)[PPL], double (&pend_val)[PPL],
+                                               uint32_t (&pend_addr)[PPL], uint32_t& pool_cnt, bool& bad) {
         constexpr int d = D;
         bool any = false;
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
-            alive[g] = alive[g] && ((uint32_t)d < maxd[g]);
-            any = any || alive[g];
-        }
-        if (__builtin_amdgcn_ballot_w64(any) == 0) return;
-        uint2 rec[PPL];
-        uint32_t c[PPL];
-#pragma unroll
-        for (int g = 0; g < PPL; ++g) {
-            c[g] = (bytes[g][d >> 2] >> ((d & 3) * 8)) & 0xFFu;
-            rec[g] = make_uint2(0u, 0u);
-            if (alive[g]) {  // finished walks issue no load
-                if (d == 0)
-                    rec[g] = W.rootc[(W.root_base ^ c[g]) & 255u];
-                else
-                    rec[g] = W.trie[(W.flags & 8u) ? (c[g] & 1u) : (base[g] ^ c[g])];  // flags: timing experiments only
-            }
-        }
-        if (COLD) {  // cold scores requested one step ago have had this step's issue time to arrive
-#pragma unroll
-            for (int g = 0; g < PPL; ++g)
+            if (COLD) {  // a cold score requested one level up came in ahead of this walk's record
                 if (pend_addr[g]) {
                     *reinterpret_cast<double*>(W.smem + pend_addr[g]) = pend_val[g];
                     pend_addr[g] = 0u;
                 }
-        }
-#pragma unroll
-        for (int g = 0; g < PPL; ++g) {
+            }
             alive[g] = alive[g] && ((rec[g].x & 0xFFu) == c[g]);
             bool term = alive[g] && (int32_t)rec[g].y < 0;
-            base[g] = rec[g].x >> 8;  // of a finished walk: never used again
+            const uint32_t base = rec[g].x >> 8;
             if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
                 if (term && d >= 1) term = W.dropout < dropout_u01(W.seed, W.s, pg[g], (uint32_t)d + 1u);
             }
@@ -117,16 +105,27 @@ struct Walk5 {
                     if (pool_cnt > W.pool_entries) bad = true;  // every row of the wave: their samples share the pool
                 }
             }
-            if (term) *reinterpret_cast<uint16_t*>(wlane[g] + d * 32) = (uint16_t)ref;
+            if (term) *reinterpret_cast<uint16_t*>(W.smem + (wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u))) = (uint16_t)ref;
+            // this walk's next record
+            if (D + 1 < 16) {
+                constexpr int e = D + 1 < 16 ? D + 1 : 15;
+                alive[g] = alive[g] && ((uint32_t)e < maxd[g]);
+                c[g] = (bytes[g][e >> 2] >> ((e & 3) * 8)) & 0xFFu;
+                rec[g] = W.trie[alive[g] ? (base ^ c[g]) : 0u];
+            } else {
+                alive[g] = false;
+            }
+            any = any || alive[g];
         }
-        Walk5<DROPOUT, COLD, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, base, pend_val, pend_addr, pool_cnt, bad);
+        if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+        Walk5<DROPOUT, COLD, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pend_val, pend_addr, pool_cnt, bad);
     }
 };
 template <bool DROPOUT, bool COLD, int PPL>
 struct Walk5<DROPOUT, COLD, PPL, 16> {
     static __device__ __forceinline__ void run(const WalkCtx<PPL>&, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL],
-                                               const uint32_t (&)[PPL], unsigned char* const (&)[PPL], bool (&)[PPL], uint32_t (&)[PPL],
-                                               double (&)[PPL], uint32_t (&)[PPL], uint32_t&, bool&) {}
+                                               const uint32_t (&)[PPL], const uint32_t (&)[PPL], bool (&)[PPL], uint2 (&)[PPL],
+                                               uint32_t (&)[PPL], double (&)[PPL], uint32_t (&)[PPL], uint32_t&, bool&) {}
 };
 
 // TGX_STAMPS=1 (diagnostic runs only): s_memtime stamps around the phases of an iteration, summed per wave
@@ -141,7 +140,7 @@ struct Walk5<DROPOUT, COLD, PPL, 16> {
     }
 
 template <bool DROPOUT, bool COLD, int PPL>
-__global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode5_kernel(EncodeParams P, Encode5Params Q) {
+__global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void encode5_kernel(EncodeParams P, Encode5Params Q) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
     constexpr uint32_t SPAN = 16u * PPL;
@@ -175,8 +174,8 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode5_kernel(Encod
     for (int q = 0; q <= 4 * PPL; ++q) wn[q] = 0;
     // this lane's two 32-byte columns of every group's index buffer (what it reads, and what it resets) and
     // the entry of its own start position's 1-byte token (what it writes, + 32 bytes per further byte)
-    const uint32_t col_a = r * kE5RowStride + ((l - 1u) & 31u) * 32u, col_b = r * kE5RowStride + (l + 15u) * 32u;
-    const uint32_t wr_off = r * kE5RowStride + l * 34u;
+    const uint32_t my_col = r * kE5RowStride + ((l - 1u) & 15u) * 32u;
+    const uint32_t wr_off = Q.idx_off + wave * (PPL * kE5GroupBytes) + r * kE5RowStride + l * 2u;  // LDS byte offset, column bits clear
     uint64_t seg[5] = {0, 0, 0, 0, 0};
     uint64_t t_last = P.stamps ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
     uint32_t iters = 0;
@@ -227,28 +226,28 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode5_kernel(Encod
         // every (start, len) starts as "no token": index 0 = the table's -inf entry
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
-            uint4* ca = reinterpret_cast<uint4*>(wbase + g * kE5GroupBytes + col_a);
-            uint4* cb = reinterpret_cast<uint4*>(wbase + g * kE5GroupBytes + col_b);
-            ca[0] = make_uint4(0, 0, 0, 0);
-            ca[1] = make_uint4(0, 0, 0, 0);
-            cb[0] = make_uint4(0, 0, 0, 0);
-            cb[1] = make_uint4(0, 0, 0, 0);
+            uint4* mine = reinterpret_cast<uint4*>(wbase + g * kE5GroupBytes + my_col);
+            mine[0] = make_uint4(0, 0, 0, 0);
+            mine[1] = make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
         E5_STAMP(1)  // text window, reset
 
         // ---- match: 64 * PPL walks over the 8-byte records
-        uint32_t pg[PPL], maxd[PPL], base[PPL];
-        unsigned char* wlane[PPL];
+        uint32_t pg[PPL], maxd[PPL];
+        uint32_t wlane[PPL];
         bool alive[PPL];
+        uint2 rec[PPL];   // record of every walk's current depth (the root's children come from LDS) ...
+        uint32_t c[PPL];  // ... and the text byte it must carry
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
             pg[g] = p0 + 16u * g + l;
             const uint32_t rem = (live && pg[g] < n) ? (n - pg[g]) : 0u;
             maxd[g] = rem < LM ? rem : LM;
-            base[g] = Q.root_base;
             alive[g] = maxd[g] > 0 && !(P.flags & 1u);
-            wlane[g] = wbase + g * kE5GroupBytes + wr_off;
+            wlane[g] = wr_off + g * kE5GroupBytes;
+            c[g] = bytes[g][0] & 0xFFu;
+            rec[g] = rootc[(Q.root_base ^ c[g]) & 255u];
         }
         uint32_t pool_cnt = 0;          // wave-uniform: pool entries handed out in this iteration
         double pend_val[PPL];           // cold scores on their way from HBM ...
@@ -259,8 +258,12 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode5_kernel(Encod
             pend_addr[g] = 0u;
         }
         {
-            WalkCtx<PPL> W{trie, rootc, smem, Q.cold_scores, Q.root_base, Q.pool_entries, pool_off, s, P.flags, P.dropout, P.seed};
-            Walk5<DROPOUT, COLD, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, base, pend_val, pend_addr, pool_cnt, bad);
+            // (opaque per trip: as a loop invariant the sixteen column offsets of a lane get hoisted out of the
+            // sample loop, kept in registers and spilled)
+            uint32_t l32 = l * 32u;
+            asm volatile("" : "+v"(l32));
+            WalkCtx<PPL> W{trie, rootc, smem, Q.cold_scores, Q.root_base, Q.pool_entries, pool_off, s, P.flags, l32, P.dropout, P.seed};
+            Walk5<DROPOUT, COLD, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pend_val, pend_addr, pool_cnt, bad);
         }
         if (COLD) {
 #pragma unroll
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode5_kernel(Encod
             for (int q = 0; q <= 4 * PPL; ++q) wn[q] = np[q];
         }
 
-        // ---- relax: a lane's 16 match indices are its two columns OR-ed; the scores come from the table
+        // ---- relax: a lane's 16 match indices are 32 contiguous bytes; the scores come from the table
         uint32_t fin[PPL];
         bool reached[PPL];
 #pragma unroll
@@ -283,18 +286,17 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode5_kernel(Encod
             fin[g] = kNoStep;
             reached[g] = true;
             if (P.flags & 2u) continue;
-            const uint4* pa = reinterpret_cast<const uint4*>(wbase + g * kE5GroupBytes + col_a);
-            const uint4* pb = reinterpret_cast<const uint4*>(wbase + g * kE5GroupBytes + col_b);
-            const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
-            const uint32_t iw[8] = {a0.x | b0.x, a0.y | b0.y, a0.z | b0.z, a0.w | b0.w,
-                                    a1.x | b1.x, a1.y | b1.y, a1.z | b1.z, a1.w | b1.w};
-            double sv[16];
+            const uint4* ip = reinterpret_cast<const uint4*>(wbase + g * kE5GroupBytes + my_col);
+            const uint4 ia = ip[0], ib = ip[1];
+            const uint32_t iw[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+            // the scores of eight steps at a time (all sixteen cost 32 registers: a wave per SIMD)
+            uint32_t fhi = 0xFFF00000u;
+            double sv[8];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
                 sv[u] = *reinterpret_cast<const double*>(smem + a);
             }
-            uint32_t fhi = 0xFFF00000u;
             relax4_step<0>(sv[0], acc, bpv, fin[g], fhi);
             relax4_step<1>(sv[1], acc, bpv, fin[g], fhi);
             relax4_step<2>(sv[2], acc, bpv, fin[g], fhi);
@@ -303,14 +305,19 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode5_kernel(Encod
             relax4_step<5>(sv[5], acc, bpv, fin[g], fhi);
             relax4_step<6>(sv[6], acc, bpv, fin[g], fhi);
             relax4_step<7>(sv[7], acc, bpv, fin[g], fhi);
-            relax4_step<8>(sv[8], acc, bpv, fin[g], fhi);
-            relax4_step<9>(sv[9], acc, bpv, fin[g], fhi);
-            relax4_step<10>(sv[10], acc, bpv, fin[g], fhi);
-            relax4_step<11>(sv[11], acc, bpv, fin[g], fhi);
-            relax4_step<12>(sv[12], acc, bpv, fin[g], fhi);
-            relax4_step<13>(sv[13], acc, bpv, fin[g], fhi);
-            relax4_step<14>(sv[14], acc, bpv, fin[g], fhi);
-            relax4_step<15>(sv[15], acc, bpv, fin[g], fhi);
+#pragma unroll
+            for (int u = 8; u < 16; ++u) {
+                const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
+                sv[u - 8] = *reinterpret_cast<const double*>(smem + a);
+            }
+            relax4_step<8>(sv[0], acc, bpv, fin[g], fhi);
+            relax4_step<9>(sv[1], acc, bpv, fin[g], fhi);
+            relax4_step<10>(sv[2], acc, bpv, fin[g], fhi);
+            relax4_step<11>(sv[3], acc, bpv, fin[g], fhi);
+            relax4_step<12>(sv[4], acc, bpv, fin[g], fhi);
+            relax4_step<13>(sv[5], acc, bpv, fin[g], fhi);
+            relax4_step<14>(sv[6], acc, bpv, fin[g], fhi);
+            relax4_step<15>(sv[7], acc, bpv, fin[g], fhi);
             reached[g] = fhi != 0xFFF00000u;
         }
         __builtin_amdgcn_wave_barrier();
@@ -379,7 +386,7 @@ uint32_t encode5_lds_layout(uint32_t n_hot, uint32_t pool_entries, int waves, in
     const uint32_t score_bytes = 8u * (n_hot + 1u) + (uint32_t)waves * pool_entries * 8u;
     if (score_bytes > 65536u) return 0;
     const uint32_t ro = (score_bytes + 15u) & ~15u;
-    const uint32_t io = ro + 2048u;
+    const uint32_t io = (ro + 2048u + 511u) & ~511u;  // 512-byte aligned: see kE5RowStride
     if (root_off) *root_off = ro;
     if (idx_off) *idx_off = io;
     return io + (uint32_t)waves * (uint32_t)ppl * kE5GroupBytes;

@@ -3,6 +3,8 @@
 // O(V) scalar loops between corpus passes; they need no device.
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -12,7 +14,18 @@
 #include "trie_build.h"
 
 
+tgx_status tgx_set_error(tgx_status st, const char* msg);  // tgx_api.cpp: the message tgx_last_error() returns
+
 namespace {
+
+tgx_status perr(tgx_status st, const char* fmt, ...) {
+    char buf[256];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return tgx_set_error(st, buf);
+}
 
 // digamma — src/prune.rs:322-335
 double digamma_ref(double x) {
@@ -187,7 +200,7 @@ double tgx_digamma(double x) { return digamma_ref(x); }
 // run_m_step — src/prune.rs:124-170.  out_idx / out_score need room for V entries.
 tgx_status tgx_prune_m_step(const double* expected, const uint8_t* keep, uint32_t vocab_size, uint32_t* out_idx,
                             double* out_score, uint32_t* out_n) {
-    if (!expected || !keep || !out_idx || !out_score || !out_n) return TGX_ERR_INVALID;
+    if (!expected || !keep || !out_idx || !out_score || !out_n) return perr(TGX_ERR_INVALID, "tgx_prune_m_step: NULL argument");
     const double threshold = 0.5;  // EXPECTED_FREQUENCY_THRESHOLD
     uint32_t n = 0;
     for (uint32_t i = 0; i < vocab_size; i++) {
@@ -201,7 +214,8 @@ tgx_status tgx_prune_m_step(const double* expected, const uint8_t* keep, uint32_
     const double logsum = digamma_ref(sum);
     for (uint32_t i = 0; i < n; i++) {
         out_score[i] = digamma_ref(out_score[i]) - logsum;
-        if (std::isnan(out_score[i]) || std::isinf(out_score[i])) return TGX_ERR_INVALID;  // the reference panics
+        if (std::isnan(out_score[i]) || std::isinf(out_score[i]))  // the reference panics (src/prune.rs:152-158)
+            return perr(TGX_ERR_INVALID, "M-step: score of token %u is not finite (expected frequency %.17g, sum %.17g)", out_idx[i], std::fmax(expected[out_idx[i]], threshold), sum);
     }
     *out_n = n;
     return TGX_OK;
@@ -212,7 +226,7 @@ tgx_status tgx_prune_m_step(const double* expected, const uint8_t* keep, uint32_
 tgx_status tgx_prune_alternatives(const tgx_flat_trie* trie, const uint8_t* bytes, const uint64_t* offs,
                                   const double* scores, uint32_t vocab_size, uint8_t* always_keep,
                                   uint32_t* alt_offs, uint32_t** alt_ids) {
-    if (!trie || !offs || !scores || !always_keep || !alt_offs || !alt_ids) return TGX_ERR_INVALID;
+    if (!trie || !offs || !scores || !always_keep || !alt_offs || !alt_ids) return perr(TGX_ERR_INVALID, "tgx_prune_alternatives: NULL argument");
     // The reference walks the vocabulary serially; the tokens are independent (each gets its own lattice), so
     // contiguous id ranges go to host threads and the per-range lists are concatenated in id order: the
     // result does not depend on the number of threads.  (1.0 s at 500 000 tokens on one core.)
@@ -246,7 +260,7 @@ tgx_status tgx_prune_alternatives(const tgx_flat_trie* trie, const uint8_t* byte
     size_t total = 0;
     for (uint32_t t = 0; t < n_threads; t++) total += part[t].size();
     *alt_ids = (uint32_t*)malloc(sizeof(uint32_t) * (total ? total : 1));
-    if (!*alt_ids) return TGX_ERR_INVALID;
+    if (!*alt_ids) return perr(TGX_ERR_INVALID, "tgx_prune_alternatives: out of host memory");
     size_t base = 0;
     for (uint32_t t = 0; t < n_threads; t++) {
         const uint32_t lo = (uint32_t)((uint64_t)vocab_size * t / n_threads);
@@ -266,7 +280,7 @@ tgx_status tgx_prune_select(const uint64_t* freq, const uint8_t* keep, const uin
                             const uint32_t* alt_offs, const uint32_t* alt_ids, const double* scores,
                             uint32_t vocab_size, uint64_t n_samples, uint32_t pruned_size, uint32_t* out_idx,
                             uint32_t* out_n) {
-    if (!freq || !keep || !always_keep || !alt_offs || !scores || !out_idx || !out_n) return TGX_ERR_INVALID;
+    if (!freq || !keep || !always_keep || !alt_offs || !scores || !out_idx || !out_n) return perr(TGX_ERR_INVALID, "tgx_prune_select: NULL argument");
     uint64_t total = 0;
     for (uint32_t i = 0; i < vocab_size; i++) total += freq[i];
     const double sum_f = (double)total;
@@ -292,7 +306,8 @@ tgx_status tgx_prune_select(const uint64_t* freq, const uint8_t* keep, const uin
             for (uint32_t k = alt_offs[id]; k < alt_offs[id + 1]; k++)
                 alt_logprob += std::log((double)freq[alt_ids[k]] + f) - alt_logsum;
             const double loss = (f / (double)n_samples) * (logprob - alt_logprob);
-            if (!std::isnormal(loss)) return TGX_ERR_INVALID;  // the reference panics
+            if (!std::isnormal(loss))  // the reference panics (src/prune.rs:287-293)
+                return perr(TGX_ERR_INVALID, "prune: loss of token %u is not a normal number (frequency %.0f, loss %.17g)", id, f, loss);
             candidates.emplace_back(id, loss);
         }
     }

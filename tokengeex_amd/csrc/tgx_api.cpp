@@ -37,6 +37,13 @@ tgx_status fail(tgx_status st, const char* fmt, ...) {
     g_err_msg = buf;
     return st;
 }
+}  // namespace
+// shared with prune_host.cpp: records the message tgx_last_error() returns (thread-local)
+tgx_status tgx_set_error(tgx_status st, const char* msg) {
+    g_err_msg = msg ? msg : "";
+    return st;
+}
+namespace {
 
 #define HIP_TRY(expr)                                                                     \
     do {                                                                                  \
@@ -57,7 +64,32 @@ struct PoolEntry {
 std::mutex g_pool_mu;
 std::vector<PoolEntry> g_pool;
 size_t g_pool_bytes = 0;
-constexpr size_t kPoolMaxBytes = 96ull << 30;
+constexpr size_t kPoolMaxBytes = 64ull << 30;
+
+// hipFree of every pooled buffer of `device` (all devices if < 0); the caller's current device is kept
+void pool_trim(int device) {
+    std::vector<PoolEntry> victims;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size();) {
+            if (device < 0 || g_pool[i].device == device) {
+                victims.push_back(g_pool[i]);
+                g_pool_bytes -= g_pool[i].bytes;
+                g_pool.erase(g_pool.begin() + (long)i);
+            } else {
+                i++;
+            }
+        }
+    }
+    if (victims.empty()) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (const PoolEntry& e : victims) {
+        (void)hipSetDevice(e.device);
+        (void)hipFree(e.ptr);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
 
 hipError_t pool_alloc(int device, size_t bytes, void** out) {
     if (bytes == 0) bytes = 256;
@@ -77,7 +109,15 @@ hipError_t pool_alloc(int device, size_t bytes, void** out) {
             return hipSuccess;
         }
     }
-    return hipMalloc(out, bytes);
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory) {
+        // the pool may be what fills the device (passes of very different sizes, or memory shared with
+        // torch / RCCL allocations): give everything back and try once more
+        (void)hipGetLastError();
+        pool_trim(device);
+        e = hipMalloc(out, bytes);
+    }
+    return e;
 }
 
 size_t rounded(size_t bytes) {
@@ -85,19 +125,38 @@ size_t rounded(size_t bytes) {
     return (bytes + 255) & ~size_t(255);
 }
 
+// Pooled bytes per process: at most a quarter of the device's memory (and never more than kPoolMaxBytes).
+size_t pool_cap(int device) {
+    static size_t cap[16] = {0};
+    if (device < 0 || device >= 16) return kPoolMaxBytes;
+    if (cap[device] == 0) {
+        size_t free_b = 0, total_b = 0;
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        (void)hipSetDevice(device);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 4 * kPoolMaxBytes;
+        if (prev >= 0) (void)hipSetDevice(prev);
+        cap[device] = std::min<size_t>(kPoolMaxBytes, total_b / 4);
+    }
+    return cap[device];
+}
+
 void pool_free(int device, void* ptr, size_t bytes) {
     if (!ptr) return;
     bytes = rounded(bytes);
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool_bytes + bytes <= kPoolMaxBytes && g_pool.size() < 256) {
+        if (g_pool_bytes + bytes <= pool_cap(device) && g_pool.size() < 256) {
             g_pool.push_back(PoolEntry{ptr, bytes, device});
             g_pool_bytes += bytes;
             return;
         }
     }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     (void)hipSetDevice(device);
     (void)hipFree(ptr);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
 }
 
 struct KernelTime {
@@ -166,6 +225,9 @@ struct tgx_corpus {
     uint32_t* d_tmp = nullptr;
     uint32_t* d_counts = nullptr;
     uint32_t* d_status = nullptr;
+    // the scratch above belongs to the corpus, so a pass holds this lock too (always after its model's):
+    // two models may work on one resident corpus from two host threads (prune and merge do, src/prune.rs:48)
+    std::mutex mu;
 };
 
 struct tgx_result {
@@ -288,28 +350,24 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     const bool use5 = use4 && m->have_trie8 && !(force && strcmp(force, "rows4") == 0) &&
                       (m->hot_coverage >= 0.85 || (force && strcmp(force, "rows5") == 0));
     if (use5) {
-        int ppl = 1;
-        {
-            // positions per lane, as for encode4_kernel below: throughput against the longest sample's chain
-            const double gbps[3] = {60.0, 50.0, 34.0}, chain_ms[3] = {13.5, 10.7, 9.1};
-            double best_t = 0;
-            for (int i = 0; i < 3; i++) {
-                const double t = std::max((double)c->n_bytes / (gbps[i] * 1e6), (double)c->max_len / 65536.0 * chain_ms[i]);
-                if (i == 0 || t < best_t * 0.95) {
-                    best_t = t;
-                    ppl = 1 << i;
-                }
-            }
-        }
+        // Four positions per lane and iteration: the four walks of a lane are staggered (encode5.hip: Walk5), so
+        // more of them hide more of each other's gather latency, and four was the fastest on every corpus shape
+        // measured (profiles/r02: 1 GiB of samples <= 64 KiB / 4 KiB / 1 KiB, 256 MiB of samples <= 256 B, and the
+        // serial chain of a single 64 KiB sample).  One block of sixteen waves per CU (78 registers: six waves
+        // per SIMD would fit, the 8 KiB of match indices per wave do not); fewer waves when the score table is
+        // large, and when the batch has fewer samples than the chip has rows, so that they spread over the CUs.
+        int ppl = 4;
         if (const char* e = getenv("TGX_PPL")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) ppl = v;
         }
         int per_simd = 0;
         HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, m->has_cold, ppl, &per_simd));
-        // two blocks per CU, each with half of the waves the registers allow (a block's waves are dealt
-        // round-robin to the four SIMDs); fewer waves until the blocks' LDS fits
-        int bpc = 2, waves = std::min(16, (per_simd / 2) * 4);
+        int bpc = ppl == 4 ? 1 : 2, waves = std::min(16, (per_simd / bpc) * 4);
+        {
+            const uint64_t rows_wanted = (c->n_samples + (uint64_t)m->num_cus * bpc - 1) / ((uint64_t)m->num_cus * bpc);
+            waves = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)waves, (rows_wanted + 3) / 4));
+        }
         if (const char* e = getenv("TGX_WAVES")) {
             const int v = atoi(e);
             if (v >= 1 && v <= 16) waves = v;
@@ -319,7 +377,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             if (v >= 1 && v <= 8) bpc = v;
         }
         while (waves > 1) {
-            const uint32_t lds = tgx::encode5_lds_layout(m->n_hot, kE5PoolEntries, waves, ppl, nullptr, nullptr);
+            const uint32_t lds = tgx::encode5_lds_layout(m->n_hot, m->has_cold ? kE5PoolEntries : 0u, waves, ppl, nullptr, nullptr);
             if (lds != 0 && lds * (uint32_t)bpc <= 160u * 1024u) break;
             waves--;
         }
@@ -334,7 +392,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         q.hot = m->d_hot;
         q.root_base = m->root_base8;
         q.n_hot = m->n_hot;
-        q.pool_entries = kE5PoolEntries;
+        q.pool_entries = m->has_cold ? kE5PoolEntries : 0u;  // no pools for a vocabulary whose values all fit the table
         q.redo_count = m->d_ctrl + 6;
         q.redo_list = c->d_counts;  // free until the trace writes the token counts
         m->last_redo_samples = 0;
@@ -588,6 +646,7 @@ void tgx_last_error_detail(uint64_t* sample, uint64_t* pos, uint64_t* len) {
 int tgx_abi_version(void) { return TGX_ABI_VERSION; }
 int tgx_device_count(void) { return usable_device_count(); }
 void tgx_free(void* p) { free(p); }
+void tgx_pool_trim(int device) { pool_trim(device); }
 
 tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                             uint32_t vocab_size, int device, tgx_model** out) {
@@ -599,6 +658,7 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
     if (!out) return fail(TGX_ERR_INVALID, "tgx_model_create: out is NULL");
     *out = nullptr;
     if (vocab_size && (!offs || !scores)) return fail(TGX_ERR_INVALID, "tgx_model_create: NULL vocab");
+    if (vocab_size && !bytes && offs[vocab_size] != offs[0]) return fail(TGX_ERR_INVALID, "tgx_model_create: NULL token bytes");
     int ndev = usable_device_count();
     if (ndev <= 0) return fail(TGX_ERR_DEVICE, "no usable HIP device (gfx950 required)");
     if (device < 0 || device >= ndev)
@@ -994,6 +1054,7 @@ tgx_status tgx_encode_corpus(tgx_model* m, tgx_corpus* c, double dropout, uint64
     *out = nullptr;
     if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
     std::lock_guard<std::mutex> lk(m->mu);
+    std::lock_guard<std::mutex> lkc(c->mu);
     return encode_corpus_locked(m, c, dropout, seed, out);
 }
 
@@ -1079,6 +1140,7 @@ tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
     if (!m || !c || !freq) return fail(TGX_ERR_INVALID, "tgx_count_tokens: NULL argument");
     if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
     std::lock_guard<std::mutex> lk(m->mu);
+    std::lock_guard<std::mutex> lkc(c->mu);
     // model.encode(sample, 0.0) for every sample (src/prune.rs:218), then a histogram of the ids by
     // radix sort + run-length encode
     tgx_result* r = nullptr;
@@ -1095,6 +1157,8 @@ tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
     size_t tb1 = 0, tb2 = 0;
     const size_t kb = (size_t)T * 4 + 256;
     auto cleanup = [&](tgx_status s2) {
+        // kernels already queued may still write these buffers: no other handle may take them from the pool yet
+        if (s2 != TGX_OK) (void)hipStreamSynchronize(m->stream);
         pool_free(m->device, d_sorted, kb);
         pool_free(m->device, d_unique, kb);
         pool_free(m->device, d_cnt, kb);
@@ -1144,6 +1208,7 @@ static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pai
     if (n_total) *n_total = 0;
     if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
     std::lock_guard<std::mutex> lk(m->mu);
+    std::lock_guard<std::mutex> lkc(c->mu);
     tgx_result* r = nullptr;
     tgx_status st = encode_corpus_locked(m, c, 0.0, 0, &r);  // model.encode(sample, 0.0), merge.rs:58
     if (st != TGX_OK) return st;
@@ -1158,6 +1223,8 @@ static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pai
     size_t tb1 = 0, tb2 = 0;
     const size_t kb = (size_t)T * 8 + 256, cb = (size_t)T * 4 + 256;
     auto cleanup = [&](tgx_status s2) {
+        // kernels already queued may still write these buffers: no other handle may take them from the pool yet
+        if (s2 != TGX_OK) (void)hipStreamSynchronize(m->stream);
         pool_free(m->device, d_keys, kb);
         pool_free(m->device, d_sorted, kb);
         pool_free(m->device, d_unique, kb);
@@ -1232,6 +1299,11 @@ static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pai
         return cleanup(fail(TGX_ERR_DEVICE, "D2H copy of pair table failed"));
     uint64_t* ok = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
     uint64_t* oc = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
+    if (!ok || !oc) {
+        free(ok);
+        free(oc);
+        return cleanup(fail(TGX_ERR_DEVICE, "out of host memory (pair table of %llu entries)", (unsigned long long)runs));
+    }
     const unsigned long long low = shift < 32 ? (1ull << shift) - 1 : 0xFFFFFFFFull;
     for (unsigned int i = 0; i < runs; i++) {
         ok[i] = ((hk[i] >> shift) << 32) | (hk[i] & low);
@@ -1346,6 +1418,8 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     uint64_t *d_soffs = nullptr, *d_sbase = nullptr;
     uint32_t *d_order = nullptr, *d_ssample = nullptr;
     auto cleanup = [&](tgx_status s2) {
+        // kernels already queued may still write these buffers: no other handle may take them from the pool yet
+        if (s2 != TGX_OK) (void)hipStreamSynchronize(m->stream);
         pool_free(m->device, d_alpha, abytes);
         pool_free(m->device, d_aexp, xbytes);
         pool_free(m->device, d_exp, ebytes);
@@ -1471,20 +1545,20 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         hipMemcpyAsync(&hz, d_z, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipStreamSynchronize(m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "E-step pass failed: %s", hipGetErrorString(hipGetLastError())));
-    for (size_t t = 0; t < n_rev; t++) {
-        const uint32_t id = m->flat_rev.tokid[t];
-        if (id != tgx::kNoToken) expected[id] += h[t];
-    }
-    if (logz_sum) *logz_sum = hz;
     m->last_alg_bytes = N + 8 * (S + 1) + 8ull * m->vocab_size;
     const unsigned long long bad = m->h_ctrl[0];
-    if (bad != ~0ULL) {
+    if (bad != ~0ULL) {  // nothing of a failed pass reaches the caller's `expected`
         const uint64_t smp = ssample[bad];
         g_err_sample = smp;
         g_err_pos = g_err_len = c->h_offs[smp + 1] - c->h_offs[smp];
         return cleanup(fail(TGX_ERR_Z_NOT_NORMAL, "normalization constant is not a normal number (sample %llu, len=%llu)",
                             (unsigned long long)smp, (unsigned long long)g_err_len));  // src/prune.rs:90-96
     }
+    for (size_t t = 0; t < n_rev; t++) {
+        const uint32_t id = m->flat_rev.tokid[t];
+        if (id != tgx::kNoToken) expected[id] += h[t];
+    }
+    if (logz_sum) *logz_sum = hz;
     return cleanup(TGX_OK);
 }
 
@@ -1495,6 +1569,7 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
     if (snippet_len == 0) snippet_len = TGX_ESTEP_SNIPPET_LEN;
     if (snippet_len >= 0xFFFFFF00ull) return fail(TGX_ERR_UNSUPPORTED, "snippet_len must be below 4 GiB");
     std::lock_guard<std::mutex> lk(m->mu);
+    std::lock_guard<std::mutex> lkc(c->mu);
     HIP_TRY(hipSetDevice(m->device));
     tgx_status st = ensure_reverse_trie(m);
     if (st != TGX_OK) return st;
@@ -1511,6 +1586,8 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
     const size_t abytes = (size_t)(N + S + 128) * 8, ebytes = (size_t)(n_rep + 1) * n_rev * 8 + 256;
     double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr;
     auto cleanup = [&](tgx_status s2) {
+        // kernels already queued may still write these buffers: no other handle may take them from the pool yet
+        if (s2 != TGX_OK) (void)hipStreamSynchronize(m->stream);
         pool_free(m->device, d_alpha, abytes);
         pool_free(m->device, d_exp, ebytes);
         pool_free(m->device, d_z, 256);
