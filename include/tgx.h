@@ -93,6 +93,29 @@ int tgx_model_device(const tgx_model *m);
 tgx_status tgx_common_prefix_search(const tgx_model *m, const uint8_t *s, uint64_t n,
                                     uint32_t *ids, uint32_t *lens, uint64_t cap, uint64_t *count);
 
+/* ---- Tokenizer front and back over packed buffers (host code, no device; csrc/frontback.cpp) ----------
+ * The reference runs these per sample on its rayon workers: the special-token splitter
+ * (src/tokenizer.rs:299-347), CrlfProcessor::preprocess (src/processor.rs:46-54), the assembly of a
+ * sample's ids from its segments (src/tokenizer.rs:65-90) and decode_batch (src/tokenizer.rs:126-187 over
+ * src/model.rs:146-160, String::from_utf8_lossy per run of base ids).  Strings cross as UTF-8 bytes +
+ * u64 offsets.  Arrays returned through pointer-to-pointer arguments are malloc'd: tgx_free. */
+tgx_status tgx_split_specials(const uint8_t *text, const uint64_t *offs, uint64_t n_samples,
+                              const uint8_t *special_bytes, const uint64_t *special_offs, uint32_t n_specials,
+                              uint64_t *seg_offs, uint64_t **seg_begin, uint64_t **seg_end,
+                              int32_t **seg_special, uint64_t *n_segments);
+tgx_status tgx_pack_segments(const uint8_t *text, const uint64_t *seg_begin, const uint64_t *seg_end,
+                             const int32_t *seg_special, uint64_t n, int crlf, uint8_t *out_text,
+                             uint64_t *out_offs, uint64_t *n_out);
+tgx_status tgx_assemble_ids(const uint64_t *seg_offs, const int32_t *seg_special, uint64_t n_samples,
+                            const uint32_t *ids, const uint64_t *id_offs, uint32_t vocab_size,
+                            uint32_t *out_ids, uint64_t *out_offs);
+tgx_status tgx_decode_batch(const uint8_t *vocab_bytes, const uint64_t *vocab_offs, uint32_t vocab_size,
+                            const uint8_t *special_bytes, const uint64_t *special_offs, uint32_t n_specials,
+                            const uint32_t *ids, const uint64_t *id_offs, uint64_t n_samples,
+                            int include_special, uint8_t **out_text, uint64_t *out_offs,
+                            uint64_t *bad_sample, uint64_t *bad_id);
+uint64_t tgx_utf8_lossy(const uint8_t *s, uint64_t n, uint8_t *out);
+
 /* ---- host-only trie introspection (no device needed) ------------------------
  * The same flattening tgx_model_create uploads, built on the host alone, so that
  * the layout can be validated (and inspected) on machines without a GPU. */

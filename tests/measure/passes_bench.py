@@ -9,16 +9,17 @@ from tokengeex_amd import synth
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 V = int(sys.argv[2]) if len(sys.argv) > 2 else 32000
 cpu_mib = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cache", f"vocab_{V}.npz")
-if os.path.exists(cache):  # tools/make_vocab_cache.py
-    z = np.load(cache)
-    o = z["offs"].astype(np.int64); fb = z["flat"].tobytes()
-    toks, scores = [fb[o[i]:o[i + 1]] for i in range(o.size - 1)], z["scores"]
+if V == 500000:  # the committed vocabulary of BASELINE.json configs[3] (tests/golden/vocab_500000.npz)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from util import load_vocab_500k
+    toks, scores = load_vocab_500k()
 else:
     vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
     toks, scores = synth.build_vocab(vflat[: 2 << 20], V, 16)
+if len(toks) != V:  # a slice too small for V tokens once produced a "500 K" record of 190 730 tokens
+    raise SystemExit(f"vocabulary has {len(toks)} tokens, {V} were asked for")
 flat, offs = synth.make_corpus(size << 20, "mixed", seed_offset=1000)
-m = tgx.NativeModel(toks, scores); c = tgx.NativeCorpus(flat, offs)
+m = tgx.NativeModel(toks, scores, for_estep=True); c = tgx.NativeCorpus(flat, offs)
 cores = len(os.sched_getaffinity(0))
 out = {"corpus_bytes": int(flat.size), "samples": int(offs.size - 1), "vocab": len(toks), "host_cores": cores}
 def timed(fn, reps=3):

@@ -431,3 +431,32 @@ def test_full_size_properties():
     want_ids, want_offs = orc.OracleModel(toks, scores).encode_batch_flat(flat[:o[k]], offs[:k + 1], threads=8)
     np.testing.assert_array_equal(ids[:t[k]], want_ids)
     np.testing.assert_array_equal(oo[:k + 1], want_offs)
+
+
+def test_native_front_end_equals_the_per_sample_python_path(monkeypatch):
+    """encode_batch through the packed-buffer front end (native special-token split, CRLF, id assembly:
+    csrc/frontback.cpp) against the per-sample Python mirror of src/tokenizer.rs:65-123, and a decode round
+    trip through the native decode_batch."""
+    flat, offs, toks, scores = corpus_and_vocab(1 << 20, "mixed", 3000, 16, seed_offset=31, max_len=4000)
+    vocab = [(t, float(s), len(t) == 1) for t, s in zip(toks, scores)]
+    specials = ["<EOS>", "<|pad|>", "\n\n\n", "<EOS_2>"]
+    tk = tgx.Tokenizer(vocab, [tgx.CrlfProcessor()], specials)
+    raw = flat.tobytes()
+    rng = np.random.default_rng(4)
+    texts = []
+    for i in range(min(400, offs.size - 1)):
+        t = raw[int(offs[i]):int(offs[i + 1])].decode("utf-8", "ignore")
+        if i % 3 == 0:
+            k = int(rng.integers(0, max(1, len(t))))
+            t = t[:k] + specials[i % 4] + t[k:] + ("\r\n" if i % 2 else "") + specials[(i + 1) % 4]
+        texts.append(t)
+    texts += ["", "<EOS>", "<EOS><EOS>", "\r\n", "a\r\nb<EOS>\r", "<EO", "<EOS_2>"]
+    got = tk.encode_batch(texts, 0.0)
+    got_ord = tk.encode_ordinary_batch(texts, 0.0)
+    monkeypatch.setattr(tgx.Tokenizer, "_native_front", lambda self: False)
+    assert got == tk.encode_batch(texts, 0.0)
+    assert got_ord == tk.encode_ordinary_batch(texts, 0.0)
+    monkeypatch.undo()
+    assert tk.decode_batch(got, True) == [t.replace("\r\n", "\n") for t in texts]
+    base = tk.base_vocab_size()
+    assert got[-1] == [base + 3] and got[-6] == [base + 0] and got[-5] == [base + 0, base + 0]

@@ -64,6 +64,11 @@ SYMBOLS = {
     "tgx_count_pairs": (_i, [_vp, _vp, _pvp, _pvp, _pu64]),
     "tgx_count_pairs_top": (_i, [_vp, _vp, _u64, _pvp, _pvp, _pu64, _pu64]),
     "tgx_estep": (_i, [_vp, _vp, _u64, _d, _u64, _vp, C.POINTER(C.c_double)]),
+    "tgx_split_specials": (_i, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _pvp, _pvp, _pvp, _pu64]),
+    "tgx_pack_segments": (_i, [_vp, _vp, _vp, _vp, _u64, _i, _vp, _vp, _pu64]),
+    "tgx_assemble_ids": (_i, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp]),
+    "tgx_decode_batch": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u64, _i, _pvp, _vp, _pu64, _pu64]),
+    "tgx_utf8_lossy": (_u64, [_vp, _u64, _vp]),
     "tgx_free": (None, [_vp]),
     "tgx_pool_trim": (None, [_i]),
     "tgx_digamma": (_d, [_d]),
@@ -136,6 +141,77 @@ def pack(items) -> tuple[np.ndarray, np.ndarray]:
         np.cumsum(np.fromiter((len(t) for t in items), dtype=np.uint64, count=len(items)), out=offs[1:])
     flat = np.frombuffer(b"".join(items), dtype=np.uint8)
     return flat, offs
+
+
+def _take(ptr_, n, ctype, dtype):
+    """Copies a malloc'd array of n elements out of the library and frees it."""
+    if not ptr_ or n == 0:
+        if ptr_:
+            lib.tgx_free(ptr_)
+        return np.zeros(0, dtype)
+    a = np.ctypeslib.as_array(C.cast(ptr_, C.POINTER(ctype)), shape=(n,)).copy()
+    lib.tgx_free(ptr_)
+    return a
+
+
+def split_specials_flat(flat: np.ndarray, offs: np.ndarray, specials: list[bytes]):
+    """SpecialTokenSplitter over a packed batch -> (seg_offs u64[S+1], seg_begin, seg_end u64[M], seg_special i32[M])."""
+    sflat, soffs = pack(specials)
+    n = offs.shape[0] - 1
+    seg_offs = np.zeros(n + 1, np.uint64)
+    sb, se, ss, m = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    check(lib.tgx_split_specials(ptr(flat) if flat.size else None, ptr(offs), n, ptr(sflat) if sflat.size else None, ptr(soffs),
+                                 len(specials), ptr(seg_offs), C.byref(sb), C.byref(se), C.byref(ss), C.byref(m)))
+    k = m.value
+    return seg_offs, _take(sb, k, C.c_uint64, np.uint64), _take(se, k, C.c_uint64, np.uint64), _take(ss, k, C.c_int32, np.int32)
+
+
+def pack_segments(flat: np.ndarray, seg_begin: np.ndarray, seg_end: np.ndarray, seg_special, crlf: bool):
+    """The non-special segments back to back, CRLF-normalised on the way if asked -> (flat, offs)."""
+    n = seg_begin.shape[0]
+    total = int((seg_end.astype(np.int64) - seg_begin.astype(np.int64)).sum()) if n else 0
+    out = np.empty(max(total, 1), np.uint8)
+    out_offs = np.zeros(n + 1, np.uint64)
+    m = C.c_uint64()
+    check(lib.tgx_pack_segments(ptr(flat) if flat.size else None, ptr(seg_begin), ptr(seg_end),
+                                None if seg_special is None else ptr(seg_special), n, 1 if crlf else 0, ptr(out), ptr(out_offs),
+                                C.byref(m)))
+    out_offs = out_offs[: m.value + 1]
+    return out[: int(out_offs[-1])], out_offs
+
+
+def assemble_ids(seg_offs: np.ndarray, seg_special: np.ndarray, ids: np.ndarray, id_offs: np.ndarray, vocab_size: int):
+    n = seg_offs.shape[0] - 1
+    n_special = int((seg_special >= 0).sum()) if seg_special.size else 0
+    out = np.empty(max(1, ids.shape[0] + n_special), np.uint32)
+    out_offs = np.zeros(n + 1, np.uint64)
+    check(lib.tgx_assemble_ids(ptr(seg_offs), ptr(seg_special) if seg_special.size else None, n, ptr(ids) if ids.size else None,
+                               ptr(id_offs), vocab_size, ptr(out), ptr(out_offs)))
+    return out[: int(out_offs[-1])], out_offs
+
+
+def decode_batch_flat(vocab_flat, vocab_offs, vocab_size: int, special_flat, special_offs, n_specials: int,
+                      ids: np.ndarray, id_offs: np.ndarray, include_special: bool):
+    """decode_batch over packed ids -> (utf-8 bytes, offsets u64[S+1])."""
+    n = id_offs.shape[0] - 1
+    out_offs = np.zeros(n + 1, np.uint64)
+    txt, bs, bi = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    st = lib.tgx_decode_batch(ptr(vocab_flat) if vocab_flat.size else None, ptr(vocab_offs), vocab_size,
+                              ptr(special_flat) if special_flat.size else None, ptr(special_offs), n_specials,
+                              ptr(ids) if ids.size else None, ptr(id_offs), n, 1 if include_special else 0, C.byref(txt),
+                              ptr(out_offs), C.byref(bs), C.byref(bi))
+    if st != OK:
+        msg = (lib.tgx_last_error() or b"").decode("utf-8", "replace")
+        raise TokenGeeXError(msg, st, bs.value, bi.value, None)
+    return _take(txt, int(out_offs[-1]), C.c_uint8, np.uint8), out_offs
+
+
+def utf8_lossy(data: bytes) -> bytes:
+    """String::from_utf8_lossy (the library's own implementation; tests compare it with Python's)."""
+    src = np.frombuffer(data, np.uint8)
+    out = np.empty(max(1, 3 * len(data)), np.uint8)
+    n = lib.tgx_utf8_lossy(ptr(src) if len(data) else None, len(data), ptr(out))
+    return out[:n].tobytes()
 
 
 class NativeResult:

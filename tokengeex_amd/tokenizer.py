@@ -91,6 +91,12 @@ def split_special_tokens(text: str, special_tokens: list[str]) -> list[tuple[str
     return out
 
 
+def _split_rows(ids: np.ndarray, offs: np.ndarray) -> list[list[int]]:
+    flat = ids.tolist()  # one conversion for the batch, then list slices
+    o = offs.tolist()
+    return [flat[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+
+
 # ---- Tokenizer ---------------------------------------------------------------------
 
 class Tokenizer:
@@ -136,14 +142,48 @@ class Tokenizer:
     def encode_ordinary(self, text: str, dropout: float) -> list[int]:
         return self.encode_ordinary_batch([text], dropout)[0]
 
+    def _native_front(self) -> bool:
+        """The packed-buffer front end (csrc/frontback.cpp) covers the CRLF processor; a Unicode
+        normalisation form (unicodedata) keeps the per-segment Python path."""
+        return all(isinstance(p, CrlfProcessor) for p in self._processors)
+
     def encode_ordinary_batch(self, texts: list[str], dropout: float) -> list[list[int]]:
+        if self._native_front():
+            ids, offs = self.encode_batch_flat(*_lib.pack([t.encode("utf-8") for t in texts]), dropout, ordinary=True)
+            return _split_rows(ids, offs)
         segs = [self._preprocess(t).encode("utf-8") for t in texts]
         ids, offs = self._encode_segments(segs, dropout)
         return [ids[int(offs[i]):int(offs[i + 1])].tolist() for i in range(len(texts))]
 
+    def encode_batch_flat(self, flat: np.ndarray, offs: np.ndarray, dropout: float = 0.0, ordinary: bool = False):
+        """encode_batch / encode_ordinary_batch over a packed batch of UTF-8 samples (uint8 flat, uint64
+        offsets[S+1]) -> (ids uint32[T], offsets uint64[S+1]): special-token split, CRLF processor, encode and
+        the assembly of the ids all run on packed buffers in native code (src/tokenizer.rs:65-123)."""
+        if not self._native_front():
+            raise TokenGeeXError("encode_batch_flat: only the CRLF processor runs on packed buffers", _lib.ERR_UNSUPPORTED)
+        flat = np.ascontiguousarray(flat, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        crlf = len(self._processors) > 0
+        n = offs.shape[0] - 1
+        if ordinary or not self._special_tokens:
+            if crlf:
+                beg, end = np.ascontiguousarray(offs[:-1]), np.ascontiguousarray(offs[1:])
+                flat, offs = _lib.pack_segments(flat, beg, end, None, True)
+            return self.encode_ordinary_batch_flat(flat, offs, dropout) if n else (np.zeros(0, np.uint32), np.zeros(1, np.uint64))
+        seg_offs, sb, se, ss = _lib.split_specials_flat(flat, offs, [t.encode("utf-8") for t in self._special_tokens])
+        pflat, poffs = _lib.pack_segments(flat, sb, se, ss, crlf)
+        if poffs.shape[0] > 1:
+            ids, id_offs = self.encode_ordinary_batch_flat(pflat, poffs, dropout)
+        else:
+            ids, id_offs = np.zeros(0, np.uint32), np.zeros(1, np.uint64)
+        return _lib.assemble_ids(seg_offs, ss, ids, id_offs, self.base_vocab_size())
+
     def encode_batch(self, texts: list[str], dropout: float) -> list[list[int]]:
         if not self._special_tokens:
             return self.encode_ordinary_batch(texts, dropout)
+        if self._native_front():
+            ids, offs = self.encode_batch_flat(*_lib.pack([t.encode("utf-8") for t in texts]), dropout)
+            return _split_rows(ids, offs)
         base = self.base_vocab_size()
         plan, segs = [], []  # per text: list of (special id | -1)
         for t in texts:
@@ -215,8 +255,33 @@ class Tokenizer:
         out.append(self._postprocess(self._model_decode(run)))
         return "".join(out)
 
+    def _vocab_packed(self):
+        if getattr(self, "_packed", None) is None or self._packed[0] != (len(self._vocab), len(self._special_tokens)):
+            vf, vo = _lib.pack([v for v, _, _ in self._vocab])
+            sf, so = _lib.pack([t.encode("utf-8") for t in self._special_tokens])
+            self._packed = ((len(self._vocab), len(self._special_tokens)), vf, vo, sf, so)
+        return self._packed[1:]
+
+    def decode_batch_flat(self, ids: np.ndarray, offs: np.ndarray, include_special_tokens: bool):
+        """decode_batch over packed ids (uint32 ids, uint64 offsets[S+1]) -> (utf-8 bytes, offsets[S+1]), in
+        native code: src/tokenizer.rs:126-187 incl. String::from_utf8_lossy per run of base ids."""
+        vf, vo, sf, so = self._vocab_packed()
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        return _lib.decode_batch_flat(vf, vo, len(self._vocab), sf, so, len(self._special_tokens), ids, offs,
+                                      include_special_tokens)
+
     def decode_batch(self, ids: list[list[int]], include_special_tokens: bool) -> list[str]:
-        return [self.decode(x, include_special_tokens) for x in ids]
+        try:
+            flat = np.fromiter((i for row in ids for i in row), dtype=np.uint32, count=sum(len(r) for r in ids))
+        except (OverflowError, ValueError):  # negative or > 2^32 - 1: the per-sample path names the id
+            return [self.decode(x, include_special_tokens) for x in ids]
+        offs = np.zeros(len(ids) + 1, np.uint64)
+        if ids:
+            np.cumsum(np.fromiter((len(r) for r in ids), dtype=np.uint64, count=len(ids)), out=offs[1:])
+        text, to = self.decode_batch_flat(flat, offs, include_special_tokens)
+        raw = text.tobytes()
+        return [raw[int(to[i]):int(to[i + 1])].decode("utf-8") for i in range(len(ids))]
 
     # -- id / token queries: src/tokenizer.rs:189-259 --
     def token_to_id(self, token: bytes) -> int | None:
