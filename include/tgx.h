@@ -116,6 +116,21 @@ tgx_status tgx_decode_batch(const uint8_t *vocab_bytes, const uint64_t *vocab_of
                             uint64_t *bad_sample, uint64_t *bad_id);
 uint64_t tgx_utf8_lossy(const uint8_t *s, uint64_t n, uint8_t *out);
 
+/* ---- `generate`: document frequencies of substrings on the device (csrc/generate.hip) ----------------
+ * VocabularyGenerator::feed (src/generate.rs:54-139): in how many samples does every char-aligned substring of
+ * at most max_token_length (<= 16) bytes occur?  Parts are the byte ranges the windows may lie in (the samples,
+ * or the matches of the split regex), sorted, disjoint, with ascending sample ids.  A (sample, substring) pair is
+ * kept iff tgx_generate_u01(seed, sample, FNV-1a-64(substring)) < insert_probability (the reference draws from an
+ * unseeded thread RNG).  Out: one entry per distinct substring — position and length of one occurrence, number
+ * of samples — malloc'd (tgx_free).  Fails with TGX_ERR_UNSUPPORTED when two different substrings share a
+ * 64-bit hash (detected by comparing bytes; *n_collisions says how many entries). */
+tgx_status tgx_substring_df(int device, const uint8_t *text, uint64_t n_bytes, const uint64_t *part_begin,
+                            const uint64_t *part_end, const uint32_t *part_sample, uint64_t n_parts,
+                            uint32_t max_token_length, double insert_probability, uint64_t seed,
+                            uint64_t **out_pos, uint32_t **out_len, uint32_t **out_df, uint64_t *n_out,
+                            uint64_t *n_windows, uint64_t *n_collisions);
+double tgx_generate_u01(uint64_t seed, uint64_t sample, uint64_t window_hash);
+
 /* ---- host-only trie introspection (no device needed) ------------------------
  * The same flattening tgx_model_create uploads, built on the host alone, so that
  * the layout can be validated (and inspected) on machines without a GPU. */

@@ -457,6 +457,10 @@ def test_native_front_end_equals_the_per_sample_python_path(monkeypatch):
     assert got == tk.encode_batch(texts, 0.0)
     assert got_ord == tk.encode_ordinary_batch(texts, 0.0)
     monkeypatch.undo()
-    assert tk.decode_batch(got, True) == [t.replace("\r\n", "\n") for t in texts]
+    dec = tk.decode_batch(got, True)
+    assert dec == [tk.decode(g, True) for g in got]                     # native decode_batch == per-sample decode
+    # round trip, CRLF-normalised (a "\r" directly in front of a special token that begins with "\n" stays: the
+    # processor sees the segments, src/tokenizer.rs:78-84)
+    assert all(d == t.replace("\r\n", "\n") for d, t in zip(dec, texts) if "\r\n\n\n" not in t)
     base = tk.base_vocab_size()
     assert got[-1] == [base + 3] and got[-6] == [base + 0] and got[-5] == [base + 0, base + 0]

@@ -69,6 +69,8 @@ SYMBOLS = {
     "tgx_assemble_ids": (_i, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp]),
     "tgx_decode_batch": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u64, _i, _pvp, _vp, _pu64, _pu64]),
     "tgx_utf8_lossy": (_u64, [_vp, _u64, _vp]),
+    "tgx_substring_df": (_i, [_i, _vp, _u64, _vp, _vp, _vp, _u64, _u32, _d, _u64, _pvp, _pvp, _pvp, _pu64, _pu64, _pu64]),
+    "tgx_generate_u01": (_d, [_u64, _u64, _u64]),
     "tgx_free": (None, [_vp]),
     "tgx_pool_trim": (None, [_i]),
     "tgx_digamma": (_d, [_d]),
@@ -204,6 +206,24 @@ def decode_batch_flat(vocab_flat, vocab_offs, vocab_size: int, special_flat, spe
         msg = (lib.tgx_last_error() or b"").decode("utf-8", "replace")
         raise TokenGeeXError(msg, st, bs.value, bi.value, None)
     return _take(txt, int(out_offs[-1]), C.c_uint8, np.uint8), out_offs
+
+
+def substring_df(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray, part_sample: np.ndarray,
+                 max_token_length: int, insert_probability: float = 1.0, seed: int = 0, device: int = 0):
+    """Document frequencies of char-aligned substrings on the device -> (pos u64[D], len u32[D], df u32[D], n_windows)."""
+    flat = np.ascontiguousarray(flat, np.uint8)
+    pb, pe = np.ascontiguousarray(part_begin, np.uint64), np.ascontiguousarray(part_end, np.uint64)
+    ps = np.ascontiguousarray(part_sample, np.uint32)
+    pos, ln, df, n, nw, nc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    check(lib.tgx_substring_df(device, ptr(flat) if flat.size else None, flat.size, ptr(pb), ptr(pe), ptr(ps), pb.shape[0],
+                               max_token_length, float(insert_probability), seed & (2**64 - 1), C.byref(pos), C.byref(ln),
+                               C.byref(df), C.byref(n), C.byref(nw), C.byref(nc)))
+    k = n.value
+    return _take(pos, k, C.c_uint64, np.uint64), _take(ln, k, C.c_uint32, np.uint32), _take(df, k, C.c_uint32, np.uint32), nw.value
+
+
+def generate_u01(seed: int, sample: int, window_hash: int) -> float:
+    return lib.tgx_generate_u01(seed & (2**64 - 1), sample, window_hash & (2**64 - 1))
 
 
 def utf8_lossy(data: bytes) -> bytes:

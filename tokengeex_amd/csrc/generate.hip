@@ -1,0 +1,366 @@
+// Device side of `generate` (reference src/generate.rs:54-139, VocabularyGenerator::feed): the DOCUMENT
+// frequency of every char-aligned substring of at most max_token_length bytes — in how many samples it occurs
+// at least once — over a packed batch.  The reference enumerates the windows per sample on rayon workers into
+// a HashSet<&str> and merges per-chunk maps; here
+//
+//   window kernels : one lane per byte position; a position that starts a character extends a window
+//                    character by character, hashing as it goes (FNV-1a 64), and keeps a window with the
+//                    seeded insert-probability rule (the reference draws from an unseeded thread RNG,
+//                    src/generate.rs:88,112: a counter hash of (seed, sample, window hash) stands in, the same
+//                    in the Python mirror).  Pass 1 counts the kept windows per block of 256 positions, an
+//                    exclusive scan gives every block its output range, pass 2 writes {hash, sample | position
+//                    | length} in position order — hence in ascending sample order.
+//   sort           : rocPRIM radix sort of the pairs by hash (stable: samples stay ascending inside a hash run).
+//   runs           : a run of equal hashes is one substring; its document frequency is the number of distinct
+//                    samples in the run (adjacent duplicates after the stable sort).  Run heads are numbered by
+//                    an inclusive scan; every entry compares its window's BYTES with its run's first entry,
+//                    so a 64-bit hash collision is detected, never silently merged.
+//
+// What stays on the host, as in the reference: the split regex (parts arrive as byte ranges), the allow regex
+// (a pure function of the candidate: applied to the distinct substrings that come back instead of to every
+// window) and the added / suggested tokens.  HBM-bound byte and integer work; no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "../../include/tgx.h"
+
+tgx_status tgx_set_error(tgx_status st, const char* msg);  // tgx_api.cpp
+
+namespace tgx {
+
+constexpr uint64_t kFnvOffset = 0xCBF29CE484222325ULL, kFnvPrime = 0x100000001B3ULL;
+
+// same function as tgx_generate_u01 below and tokengeex_amd/generate.py::_u01
+__host__ __device__ inline double generate_u01(uint64_t seed, uint64_t sample, uint64_t h) {
+    uint64_t x = seed ^ (sample * 0x9E3779B97F4A7C15ULL) ^ (h * 0xC2B2AE3D27D4EB4FULL);
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBULL;
+    x ^= x >> 31;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct WindowParams {
+    const uint8_t* text;          // padded: reads up to 32 bytes past a position are safe
+    uint64_t n_bytes;
+    const uint64_t* part_begin;   // parts (samples, or the split regex's matches) sorted, disjoint
+    const uint64_t* part_end;
+    const uint32_t* part_sample;
+    uint64_t n_parts;
+    const uint32_t* blk_part;     // per block of 256 positions: first part whose end lies beyond the block's start
+    uint32_t max_len;
+    double prob;
+    uint64_t seed;
+    uint32_t* blk_count;          // pass 1: kept windows per block
+    const uint64_t* blk_offs;     // pass 2: exclusive scan of blk_count
+    uint64_t* keys;               // pass 2: window hash
+    uint64_t* vals;               // pass 2: sample << 37 | position << 5 | (length - 1)
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(256) void window_kernel(WindowParams P) {
+    __shared__ uint32_t wave_cnt[4];
+    const uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t sample = 0;
+    uint64_t end = 0;  // end of this position's part; 0 = the position starts no window
+    if (p < P.n_bytes) {
+        uint64_t k = P.blk_part[blockIdx.x];
+        while (k < P.n_parts && P.part_end[k] <= p) k++;
+        if (k < P.n_parts && P.part_begin[k] <= p && (P.text[p] & 0xC0u) != 0x80u) {  // inside a part, at a character start
+            end = P.part_end[k];
+            sample = P.part_sample[k];
+        }
+    }
+    // the windows of this position in ascending length; `emit` is called for the kept ones (src/generate.rs:99-120)
+    auto windows = [&](auto emit) {
+        uint32_t kept = 0;
+        uint64_t h = kFnvOffset;
+        for (uint32_t len = 1; len <= P.max_len && p + len <= end; ++len) {
+            h = (h ^ (uint64_t)P.text[p + len - 1]) * kFnvPrime;
+            const bool boundary = (p + len == end) || (P.text[p + len] & 0xC0u) != 0x80u;
+            if (boundary && (P.prob >= 1.0 || generate_u01(P.seed, sample, h) < P.prob)) {
+                emit(kept, h, len);
+                kept++;
+            }
+        }
+        return kept;
+    };
+    const uint32_t kept = windows([](uint32_t, uint64_t, uint32_t) {});
+    // block-level exclusive prefix of `kept` (position order)
+    uint32_t incl = kept;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t y = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += y;
+    }
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_cnt[w];
+    if (!EMIT) {
+        if (threadIdx.x == 255) P.blk_count[blockIdx.x] = before + incl;
+        return;
+    }
+    const uint64_t at = P.blk_offs[blockIdx.x] + before + (incl - kept);
+    windows([&](uint32_t i, uint64_t h, uint32_t len) {
+        P.keys[at + i] = h;
+        P.vals[at + i] = ((uint64_t)sample << 37) | (p << 5) | (uint64_t)(len - 1u);
+    });
+}
+
+// head[i] = 1 where a new hash run starts
+__global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ head) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t j = i ? i - 1 : 0;
+    head[i] = ((i == 0) | (keys[i] != keys[j])) ? 1u : 0u;
+}
+
+// rep[run] = the run's first entry; df[run] += 1 for every entry that opens a new sample inside its run.
+// (Straight-line on purpose: written with short-circuit loads of entry i - 1, hipcc 7.2 kept the run index in a
+// register pair that the merged 16-byte load of keys[i - 1 .. i] overwrites on one path, and the atomic went
+// to a wild address.)
+__global__ __launch_bounds__(256) void run_count_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals,
+                                                        const uint32_t* __restrict__ run_id, uint64_t n, uint32_t n_runs,
+                                                        uint64_t* __restrict__ rep, uint32_t* __restrict__ df) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t j = i ? i - 1 : 0;
+    const uint64_t k = keys[i], kp = keys[j], v = vals[i], vp = vals[j];
+    const uint32_t r = run_id[i] - 1u;
+    const bool head = (i == 0) | (k != kp);
+    const bool newdoc = head | ((v >> 37) != (vp >> 37));
+    if (r >= n_runs) return;  // cannot happen (run ids are an inclusive scan of the heads); never index with it
+    if (head) rep[r] = v;
+    if (newdoc) atomicAdd(&df[r], 1u);
+}
+
+// every entry's window against its run's representative, byte by byte
+__global__ __launch_bounds__(256) void run_check_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ vals,
+                                                        const uint32_t* __restrict__ run_id, uint64_t n, uint32_t n_runs,
+                                                        const uint64_t* __restrict__ rep, unsigned long long* __restrict__ collisions) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (run_id[i] - 1u >= n_runs) return;
+    const uint64_t a = vals[i], b = rep[run_id[i] - 1u];
+    if (a == b) return;
+    const uint32_t la = (uint32_t)(a & 31u) + 1u, lb = (uint32_t)(b & 31u) + 1u;
+    bool same = la == lb;
+    const uint64_t pa = (a >> 5) & 0xFFFFFFFFull, pb = (b >> 5) & 0xFFFFFFFFull;
+    for (uint32_t j = 0; same && j < la; ++j) same = text[pa + j] == text[pb + j];
+    if (!same) atomicAdd(collisions, 1ull);
+}
+
+}  // namespace tgx
+
+extern "C" {
+
+double tgx_generate_u01(uint64_t seed, uint64_t sample, uint64_t window_hash) { return tgx::generate_u01(seed, sample, window_hash); }
+
+// Document frequencies of the char-aligned substrings of at most max_token_length (<= 16) bytes of the parts
+// text[part_begin[k], part_end[k]) (sorted, disjoint; part_sample[k] non-decreasing), kept with probability
+// insert_probability per (sample, substring).  Out: one entry per distinct substring — the position and length
+// of one occurrence and the number of samples it occurs in — malloc'd (tgx_free), in ascending order of the
+// substrings' FNV-1a hashes.  *n_collisions > 0 (two different substrings with one 64-bit hash) makes the
+// call fail with TGX_ERR_UNSUPPORTED: callers fall back to the host path.  text must be < 4 GiB.
+tgx_status tgx_substring_df(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
+                            const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
+                            uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t** out_pos,
+                            uint32_t** out_len, uint32_t** out_df, uint64_t* n_out, uint64_t* n_windows,
+                            uint64_t* n_collisions) {
+    using namespace tgx;
+    if (!out_pos || !out_len || !out_df || !n_out) return tgx_set_error(TGX_ERR_INVALID, "tgx_substring_df: NULL argument");
+    *out_pos = nullptr;
+    *out_len = nullptr;
+    *out_df = nullptr;
+    *n_out = 0;
+    if (n_windows) *n_windows = 0;
+    if (n_collisions) *n_collisions = 0;
+    if (n_parts && (!text || !part_begin || !part_end || !part_sample)) return tgx_set_error(TGX_ERR_INVALID, "tgx_substring_df: NULL argument");
+    if (max_token_length < 1 || max_token_length > 16) return tgx_set_error(TGX_ERR_UNSUPPORTED, "tgx_substring_df: max_token_length must be 1..16");
+    if (n_bytes >= (1ull << 32)) return tgx_set_error(TGX_ERR_UNSUPPORTED, "tgx_substring_df: feed at most 4 GiB per call");
+    if (n_parts == 0 || n_bytes == 0) return TGX_OK;
+    for (uint64_t k = 0; k < n_parts; k++) {
+        if (part_end[k] < part_begin[k] || part_end[k] > n_bytes || (k && part_begin[k] < part_end[k - 1]) ||
+            (k && part_sample[k] < part_sample[k - 1]) || part_sample[k] >= (1u << 27))
+            return tgx_set_error(TGX_ERR_INVALID, "tgx_substring_df: parts must be sorted, disjoint, inside the text, with ascending sample ids below 2^27");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        (void)hipGetLastError();
+        return tgx_set_error(TGX_ERR_DEVICE, "no usable HIP device (gfx950 required)");
+    }
+    std::vector<void*> owned;
+    auto fail = [&](tgx_status st, const char* msg) {
+        (void)hipDeviceSynchronize();
+        for (void* p : owned) (void)hipFree(p);
+        return tgx_set_error(st, msg);
+    };
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess) return nullptr;
+        owned.push_back(p);
+        return p;
+    };
+    const bool dbg = getenv("TGX_DEBUG") != nullptr;
+#define G_TRY(expr)                                                       \
+    do {                                                                  \
+        if (dbg) { fprintf(stderr, "[tgx] generate: %s\n", #expr); fflush(stderr); } \
+        if ((expr) != hipSuccess) return fail(TGX_ERR_DEVICE, "HIP error in tgx_substring_df: " #expr); \
+        if (dbg && hipDeviceSynchronize() != hipSuccess) return fail(TGX_ERR_DEVICE, "HIP error after " #expr); \
+    } while (0)
+    G_TRY(hipSetDevice(device));
+    const uint64_t n_blocks = (n_bytes + 255) / 256;
+    // first part whose end lies beyond each block's start
+    std::vector<uint32_t> blk_part(n_blocks);
+    {
+        uint64_t k = 0;
+        for (uint64_t b = 0; b < n_blocks; b++) {
+            while (k < n_parts && part_end[k] <= b * 256) k++;
+            blk_part[b] = (uint32_t)std::min<uint64_t>(k, 0xFFFFFFFFull);
+        }
+    }
+    uint8_t* d_text = (uint8_t*)dalloc(n_bytes + 64);
+    uint64_t* d_pb = (uint64_t*)dalloc(n_parts * 8);
+    uint64_t* d_pe = (uint64_t*)dalloc(n_parts * 8);
+    uint32_t* d_ps = (uint32_t*)dalloc(n_parts * 4);
+    uint32_t* d_bp = (uint32_t*)dalloc(n_blocks * 4);
+    uint32_t* d_bc = (uint32_t*)dalloc(n_blocks * 4);
+    uint64_t* d_bo = (uint64_t*)dalloc((n_blocks + 1) * 8);
+    unsigned long long* d_ctr = (unsigned long long*)dalloc(64);
+    if (!d_text || !d_pb || !d_pe || !d_ps || !d_bp || !d_bc || !d_bo || !d_ctr) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
+    G_TRY(hipMemset(d_text + n_bytes, 0, 64));
+    G_TRY(hipMemcpy(d_text, text, n_bytes, hipMemcpyHostToDevice));
+    G_TRY(hipMemcpy(d_pb, part_begin, n_parts * 8, hipMemcpyHostToDevice));
+    G_TRY(hipMemcpy(d_pe, part_end, n_parts * 8, hipMemcpyHostToDevice));
+    G_TRY(hipMemcpy(d_ps, part_sample, n_parts * 4, hipMemcpyHostToDevice));
+    G_TRY(hipMemcpy(d_bp, blk_part.data(), n_blocks * 4, hipMemcpyHostToDevice));
+    G_TRY(hipMemset(d_ctr, 0, 64));
+    WindowParams P{};
+    P.text = d_text;
+    P.n_bytes = n_bytes;
+    P.part_begin = d_pb;
+    P.part_end = d_pe;
+    P.part_sample = d_ps;
+    P.n_parts = n_parts;
+    P.blk_part = d_bp;
+    P.max_len = max_token_length;
+    P.prob = insert_probability;
+    P.seed = seed;
+    P.blk_count = d_bc;
+    hipLaunchKernelGGL(window_kernel<false>, dim3((uint32_t)n_blocks), dim3(256), 0, 0, P);
+    G_TRY(hipGetLastError());
+    // exclusive scan of the block counts (u32 -> u64)
+    {
+        size_t tb = 0;
+        G_TRY((rocprim::exclusive_scan(nullptr, tb, d_bc, d_bo, (uint64_t)0, (size_t)n_blocks, rocprim::plus<uint64_t>())));
+        void* tmp = dalloc(tb);
+        if (!tmp) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
+        G_TRY((rocprim::exclusive_scan(tmp, tb, d_bc, d_bo, (uint64_t)0, (size_t)n_blocks, rocprim::plus<uint64_t>())));
+    }
+    uint64_t last_off = 0;
+    uint32_t last_cnt = 0;
+    G_TRY(hipMemcpy(&last_off, d_bo + (n_blocks - 1), 8, hipMemcpyDeviceToHost));
+    G_TRY(hipMemcpy(&last_cnt, d_bc + (n_blocks - 1), 4, hipMemcpyDeviceToHost));
+    const uint64_t M = last_off + last_cnt;
+    if (n_windows) *n_windows = M;
+    if (M == 0) {
+        for (void* p : owned) (void)hipFree(p);
+        return TGX_OK;
+    }
+    if (M >= (1ull << 32)) return fail(TGX_ERR_UNSUPPORTED, "tgx_substring_df: more than 2^32 windows in one call: feed smaller batches");
+    uint64_t* d_keys = (uint64_t*)dalloc(M * 8);
+    uint64_t* d_vals = (uint64_t*)dalloc(M * 8);
+    uint64_t* d_keys2 = (uint64_t*)dalloc(M * 8);
+    uint64_t* d_vals2 = (uint64_t*)dalloc(M * 8);
+    if (!d_keys || !d_vals || !d_keys2 || !d_vals2) return fail(TGX_ERR_DEVICE, "out of device memory (generate: windows)");
+    P.blk_offs = d_bo;
+    P.keys = d_keys;
+    P.vals = d_vals;
+    hipLaunchKernelGGL(window_kernel<true>, dim3((uint32_t)n_blocks), dim3(256), 0, 0, P);
+    G_TRY(hipGetLastError());
+    {
+        size_t tb = 0;
+        G_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, (size_t)M));
+        void* tmp = dalloc(tb);
+        if (!tmp) return fail(TGX_ERR_DEVICE, "out of device memory (generate: sort)");
+        G_TRY(rocprim::radix_sort_pairs(tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (size_t)M));
+    }
+    // run ids: inclusive scan of the run heads (the unsorted key buffer is free now)
+    uint32_t* d_head = reinterpret_cast<uint32_t*>(d_keys);
+    uint32_t* d_run = reinterpret_cast<uint32_t*>(d_keys) + M;
+    const uint32_t mblocks = (uint32_t)((M + 255) / 256);
+    hipLaunchKernelGGL(run_heads_kernel, dim3(mblocks), dim3(256), 0, 0, d_keys2, M, d_head);
+    G_TRY(hipGetLastError());
+    {
+        size_t tb = 0;
+        G_TRY((rocprim::inclusive_scan(nullptr, tb, d_head, d_run, (size_t)M, rocprim::plus<uint32_t>())));
+        void* tmp = dalloc(tb);
+        if (!tmp) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
+        G_TRY((rocprim::inclusive_scan(tmp, tb, d_head, d_run, (size_t)M, rocprim::plus<uint32_t>())));
+    }
+    uint32_t n_runs = 0;
+    G_TRY(hipMemcpy(&n_runs, d_run + (M - 1), 4, hipMemcpyDeviceToHost));
+    if (dbg) {
+        std::vector<uint32_t> hh(2 * M);
+        (void)hipMemcpy(hh.data(), d_head, 2 * M * 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[tgx] generate: M=%llu n_runs=%u heads:", (unsigned long long)M, n_runs);
+        for (uint64_t i = 0; i < std::min<uint64_t>(M, 24); i++) fprintf(stderr, " %u/%u", hh[i], hh[M + i]);
+        fprintf(stderr, "\n[tgx] generate: d_keys=%p d_vals=%p d_keys2=%p d_vals2=%p d_head=%p d_run=%p\n", (void*)d_keys, (void*)d_vals,
+                (void*)d_keys2, (void*)d_vals2, (void*)d_head, (void*)d_run);
+        if (getenv("TGX_DEBUG")[0] == '2') return fail(TGX_ERR_DEVICE, "debug stop before run_count_kernel");
+    }
+    if (n_runs == 0 || n_runs > M) return fail(TGX_ERR_DEVICE, "tgx_substring_df: inconsistent run count");
+    uint64_t* d_rep = d_vals;  // the unsorted values are free now: n_runs <= M
+    uint32_t* d_df = (uint32_t*)dalloc((size_t)n_runs * 4);
+    if (!d_df) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
+    G_TRY(hipMemset(d_df, 0, (size_t)n_runs * 4));
+    hipLaunchKernelGGL(run_count_kernel, dim3(mblocks), dim3(256), 0, 0, d_keys2, d_vals2, d_run, M, n_runs, d_rep, d_df);
+    G_TRY(hipGetLastError());
+    hipLaunchKernelGGL(run_check_kernel, dim3(mblocks), dim3(256), 0, 0, d_text, d_vals2, d_run, M, n_runs, d_rep, d_ctr);
+    G_TRY(hipGetLastError());
+    unsigned long long coll = 0;
+    G_TRY(hipMemcpy(&coll, d_ctr, 8, hipMemcpyDeviceToHost));
+    if (n_collisions) *n_collisions = coll;
+    if (coll) return fail(TGX_ERR_UNSUPPORTED, "tgx_substring_df: two different substrings share a 64-bit hash: use the host path for this batch");
+    std::vector<uint64_t> rep(n_runs);
+    uint64_t* pos = (uint64_t*)malloc(sizeof(uint64_t) * n_runs);
+    uint32_t* len = (uint32_t*)malloc(sizeof(uint32_t) * n_runs);
+    uint32_t* df = (uint32_t*)malloc(sizeof(uint32_t) * n_runs);
+    if (!pos || !len || !df) {
+        free(pos);
+        free(len);
+        free(df);
+        return fail(TGX_ERR_INVALID, "tgx_substring_df: out of host memory");
+    }
+    if (hipMemcpy(rep.data(), d_rep, (size_t)n_runs * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(df, d_df, (size_t)n_runs * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        free(pos);
+        free(len);
+        free(df);
+        return fail(TGX_ERR_DEVICE, "tgx_substring_df: copy of the result failed");
+    }
+    for (uint32_t r = 0; r < n_runs; r++) {
+        pos[r] = (rep[r] >> 5) & 0xFFFFFFFFull;
+        len[r] = (uint32_t)(rep[r] & 31u) + 1u;
+    }
+    for (void* p : owned) (void)hipFree(p);
+#undef G_TRY
+    *out_pos = pos;
+    *out_len = len;
+    *out_df = df;
+    *n_out = n_runs;
+    return TGX_OK;
+}
+
+}  // extern "C"
