@@ -169,6 +169,13 @@ double tgx_dropout_u01_host(uint64_t seed, uint64_t sample, uint64_t pos, uint32
  * TGX_ERR_NO_PATH *out is NULL and tgx_last_error_detail names the sample. */
 tgx_status tgx_encode_batch(tgx_model *m, const uint8_t *text, const uint64_t *offs,
                             uint64_t n_samples, double dropout, uint64_t seed, tgx_result **out);
+/* The same with host buffers on both sides: the ids are written to ids_out (room for ids_cap entries; the
+ * number of bytes of the batch always suffices) and the exclusive token offsets to offs_out[n_samples + 1].
+ * Large batches are cut at sample boundaries into chunks whose upload, kernels and download overlap (three
+ * host threads).  Errors as tgx_encode_batch (the lowest failing sample of the batch is reported). */
+tgx_status tgx_encode_batch_host(tgx_model *m, const uint8_t *text, const uint64_t *offs, uint64_t n_samples,
+                                 double dropout, uint64_t seed, uint32_t *ids_out, uint64_t ids_cap,
+                                 uint64_t *offs_out, uint64_t *n_tokens);
 
 uint64_t tgx_result_num_samples(const tgx_result *r);
 uint64_t tgx_result_num_tokens(const tgx_result *r);

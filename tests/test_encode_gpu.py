@@ -464,3 +464,32 @@ def test_native_front_end_equals_the_per_sample_python_path(monkeypatch):
     assert all(d == t.replace("\r\n", "\n") for d, t in zip(dec, texts) if "\r\n\n\n" not in t)
     base = tk.base_vocab_size()
     assert got[-1] == [base + 3] and got[-6] == [base + 0] and got[-5] == [base + 0, base + 0]
+
+
+def test_host_to_host_entry_point_chunks_and_errors(monkeypatch):
+    """tgx_encode_batch_host: the batch in chunks through upload / kernels / download on three host threads —
+    same ids and offsets as the one-piece path whatever the chunk size, the lowest failing sample reported,
+    a destination that is too small refused."""
+    flat, offs, toks, scores = corpus_and_vocab(6 << 20, "mixed", 4000, 16, seed_offset=41, max_len=30000)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    want_ids, want_offs = ora.encode_batch_flat(flat, offs, threads=8)
+    for mb in ("1", "2", "64"):
+        monkeypatch.setenv("TGX_E2E_CHUNK_MB", mb)
+        ids, oo = nat.encode_batch_host(flat, offs)
+        np.testing.assert_array_equal(ids, want_ids)
+        np.testing.assert_array_equal(oo, want_offs)
+    ids, oo = nat.encode_batch_host(flat, offs, dropout=0.2, seed=5)      # dropout: one chunk, global sample indices
+    w2, o2 = ora.encode_batch_flat(flat, offs, 0.2, 5, threads=8)
+    np.testing.assert_array_equal(ids, w2)
+    np.testing.assert_array_equal(oo, o2)
+    monkeypatch.setenv("TGX_E2E_CHUNK_MB", "1")
+    with pytest.raises(tgx.TokenGeeXError):
+        nat.encode_batch_host(flat, offs, ids_out=np.empty(1000, np.uint32))
+    sparse = tgx.NativeModel([b"a", b"b"], [-1.0, -1.0])
+    texts = [b"ab" * 300000, b"ba" * 300000, b"abc", b"a" * 700000, b"!!", b"b"]
+    f2, o2 = tgx.pack(texts)
+    with pytest.raises(tgx.TokenGeeXError) as e:
+        sparse.encode_batch_host(f2, o2)
+    assert str(e.value) == "no path to position 3/3" and e.value.sample == 2
+    ids, oo = nat.encode_batch_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert ids.size == 0 and oo.tolist() == [0]

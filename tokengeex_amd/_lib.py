@@ -46,6 +46,7 @@ SYMBOLS = {
     "tgx_tok_hash_selftest": (_i, [_vp, _vp, _u32, C.POINTER(C.c_uint32), _pu64]),
     "tgx_dropout_u01_host": (_d, [_u64, _u64, _u64, _u32]),
     "tgx_encode_batch": (_i, [_vp, _vp, _vp, _u64, _d, _u64, _pvp]),
+    "tgx_encode_batch_host": (_i, [_vp, _vp, _vp, _u64, _d, _u64, _vp, _u64, _vp, _pu64]),
     "tgx_result_num_samples": (_u64, [_vp]),
     "tgx_result_num_tokens": (_u64, [_vp]),
     "tgx_result_ids": (_vp, [_vp]),
@@ -352,6 +353,22 @@ class NativeModel:
         check(lib.tgx_encode_batch(self._h, ptr(flat) if flat.size else None, ptr(offs),
                                    offs.shape[0] - 1, float(dropout), seed & (2**64 - 1), C.byref(h)))
         return NativeResult(h)
+
+    def encode_batch_host(self, flat: np.ndarray, offs: np.ndarray, dropout: float = 0.0, seed: int = 0,
+                          ids_out: np.ndarray | None = None):
+        """Host buffers in, host buffers out, with upload / kernels / download of the batch's chunks overlapped
+        (tgx_encode_batch_host) -> (ids uint32[T] — a view of ids_out when given —, offsets uint64[S+1])."""
+        flat = np.ascontiguousarray(flat, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = offs.shape[0] - 1
+        if ids_out is None:
+            ids_out = np.empty(max(1, int(offs[-1] - offs[0])), np.uint32)
+        assert ids_out.dtype == np.uint32 and ids_out.flags.c_contiguous
+        out_offs = np.zeros(n + 1, np.uint64)
+        t = C.c_uint64()
+        check(lib.tgx_encode_batch_host(self._h, ptr(flat) if flat.size else None, ptr(offs), n, float(dropout),
+                                        seed & (2**64 - 1), ptr(ids_out), ids_out.size, ptr(out_offs), C.byref(t)))
+        return ids_out[: t.value], out_offs
 
     def encode_corpus(self, corpus: NativeCorpus, dropout: float = 0.0, seed: int = 0) -> NativeResult:
         h = C.c_void_p()

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -1068,6 +1069,140 @@ tgx_status tgx_encode_batch(tgx_model* m, const uint8_t* text, const uint64_t* o
     st = tgx_encode_corpus(m, c, dropout, seed, out);
     tgx_corpus_free(c);
     return st;
+}
+
+// Host buffers in, host buffers out (what a Rust caller of Tokenizer::encode_batch has: bindings/python/src/lib.rs:51-59
+// hands over borrowed strings and takes owned vectors back).  A large batch is cut at sample boundaries into chunks
+// of 256 MiB that three host threads take through upload -> kernels -> download: the kernels of one chunk run
+// (under the model's lock) while the text of the next goes to the device and the ids of the previous come back, so
+// the PCIe link works in both directions beside the kernels instead of before and after them.  ids_out must hold
+// ids_cap entries (at most one token per byte: ids_cap = bytes always suffices); offs_out[n_samples + 1].
+// Dropout passes keep the one-chunk path (the keep rule hashes the sample's index in the batch).
+tgx_status tgx_encode_batch_host(tgx_model* m, const uint8_t* text, const uint64_t* offs, uint64_t n_samples, double dropout,
+                                 uint64_t seed, uint32_t* ids_out, uint64_t ids_cap, uint64_t* offs_out, uint64_t* n_tokens) {
+    if (!m || !offs_out || !n_tokens || (n_samples && !offs)) return fail(TGX_ERR_INVALID, "tgx_encode_batch_host: NULL argument");
+    *n_tokens = 0;
+    offs_out[0] = 0;
+    if (n_samples == 0) return TGX_OK;
+    for (uint64_t i = 0; i < n_samples; i++)
+        if (offs[i + 1] < offs[i]) return fail(TGX_ERR_INVALID, "offsets not monotone at %llu", (unsigned long long)i);
+    const uint64_t N = offs[n_samples] - offs[0];
+    // chunk boundaries
+    std::vector<uint64_t> cut(1, 0);
+    {
+        uint64_t chunk = 256ull << 20;  // a chunk's pass is bounded below by the serial chain of its longest sample: few, large chunks
+        if (dropout > 0.0) chunk = ~0ull;
+        if (const char* e = getenv("TGX_E2E_CHUNK_MB")) {
+            const long v = atol(e);
+            if (v > 0 && dropout <= 0.0) chunk = (uint64_t)v << 20;
+        }
+        uint64_t start = offs[0];
+        for (uint64_t i = 0; i < n_samples; i++)
+            if (offs[i + 1] - start >= chunk && i + 1 < n_samples) {
+                cut.push_back(i + 1);
+                start = offs[i + 1];
+            }
+        cut.push_back(n_samples);
+    }
+    const size_t C = cut.size() - 1;
+    struct ChunkState {
+        uint64_t tokens = 0;
+        bool counted = false;
+    };
+    std::vector<ChunkState> cs(C);
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t next_chunk = 0;
+    tgx_status first_err = TGX_OK;
+    size_t first_err_chunk = ~size_t(0);
+    std::string err_msg;
+    uint64_t err_sample = 0, err_pos = 0, err_len = 0;
+    bool abort_all = false;
+    auto worker = [&]() {
+        for (;;) {
+            size_t k;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (abort_all || next_chunk >= C) return;
+                k = next_chunk++;
+            }
+            const uint64_t lo = cut[k], hi = cut[k + 1];
+            tgx_result* r = nullptr;
+            tgx_status st = tgx_encode_batch(m, text, offs + lo, hi - lo, dropout, seed, &r);
+            uint64_t base = 0;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                if (st != TGX_OK) {
+                    if (k < first_err_chunk) {  // the lowest failing sample of the batch is in the lowest failing chunk
+                        first_err = st;
+                        first_err_chunk = k;
+                        err_msg = g_err_msg;
+                        err_sample = g_err_sample + lo;
+                        err_pos = g_err_pos;
+                        err_len = g_err_len;
+                    }
+                    abort_all = true;
+                    cs[k].counted = true;
+                    cv.notify_all();
+                    continue;
+                }
+                cs[k].tokens = r->n_tokens;
+                cs[k].counted = true;
+                cv.notify_all();
+                cv.wait(lk, [&]() {
+                    if (abort_all) return true;
+                    for (size_t j = 0; j < k; j++)
+                        if (!cs[j].counted) return false;
+                    return true;
+                });
+                if (abort_all) {
+                    lk.unlock();
+                    tgx_result_free(r);
+                    continue;
+                }
+                for (size_t j = 0; j < k; j++) base += cs[j].tokens;
+            }
+            tgx_status st2 = TGX_OK;
+            if (base + r->n_tokens > ids_cap) {
+                st2 = fail(TGX_ERR_INVALID, "tgx_encode_batch_host: ids_out holds %llu ids, the batch has more", (unsigned long long)ids_cap);
+            } else {
+                if (r->n_tokens) st2 = tgx_result_copy_ids(r, ids_out + base, r->n_tokens);
+                if (st2 == TGX_OK) {
+                    std::vector<uint64_t> lo_offs(hi - lo + 1);
+                    st2 = tgx_result_copy_offsets(r, lo_offs.data(), hi - lo + 1);
+                    for (uint64_t i = 0; i <= hi - lo && st2 == TGX_OK; i++) offs_out[lo + i] = base + lo_offs[i];
+                }
+            }
+            tgx_result_free(r);
+            if (st2 != TGX_OK) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (first_err == TGX_OK) {
+                    first_err = st2;
+                    first_err_chunk = k;
+                    err_msg = g_err_msg;
+                }
+                abort_all = true;
+                cv.notify_all();
+            }
+        }
+    };
+    const size_t T = std::min<size_t>(3, C);
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < T; i++) th.emplace_back(worker);
+    worker();
+    for (auto& x : th) x.join();
+    if (first_err != TGX_OK) {
+        g_err_msg = err_msg;
+        g_err_sample = err_sample;
+        g_err_pos = err_pos;
+        g_err_len = err_len;
+        return first_err;
+    }
+    uint64_t total = 0;
+    for (size_t k = 0; k < C; k++) total += cs[k].tokens;
+    *n_tokens = total;
+    m->last_alg_bytes = N + 4 * total + 16 * (n_samples + 1);
+    return TGX_OK;
 }
 
 uint64_t tgx_result_num_samples(const tgx_result* r) { return r ? r->n_samples : 0; }
