@@ -268,6 +268,8 @@ uint32_t tgx_last_encode_waves_per_cu(const tgx_model *m);
 /* samples the last encode of a vocabulary with tokens of 17..32 bytes had to redo with the
  * two-samples-per-wave kernel because a wave ran out of overflow entries for long matches (0 = none). */
 uint64_t tgx_last_encode_redo_samples(const tgx_model *m);
+/* samples of the last encode pass that had a block of their own (the long-sample kernel) */
+uint64_t tgx_last_encode_long_samples(const tgx_model *m);
 
 /* ---- dropout ---------------------------------------------------------------
  * The reference draws rand::random::<f64>() from an unseeded thread RNG

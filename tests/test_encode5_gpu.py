@@ -95,3 +95,43 @@ def test_edge_bytes_and_block_boundaries(monkeypatch):
     with pytest.raises(tgx.TokenGeeXError) as e:
         nat.encode_batch_flat(bad, ob)
     assert str(e.value) == "no path to position 3/3" and e.value.sample == 1
+
+
+@pytest.mark.parametrize("threshold", ["1", "300", "5000"])
+def test_long_sample_kernel_walkers_and_relaxer(monkeypatch, threshold):
+    """encode6_kernel (a block per long sample: seven walker waves fill a ring of match-index buffers ahead of
+    one relaxing wave) with the length threshold forced low, so that every / most samples take it: sample
+    lengths around the multiples of 16 and 64, empty samples, unreachable ends, dropout, more samples than
+    blocks, a 1 MiB sample — bit-exact against the oracle; the rest of the batch runs encode5_kernel."""
+    monkeypatch.setenv("TGX_LONG_THRESHOLD", threshold)
+    flat, offs, toks, scores = corpus_and_vocab(3 << 20, "mixed", 4000, 16, seed_offset=51, max_len=40000)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    assert_same_encoding(nat, ora, flat, offs)
+    kt = nat.last_kernel_times()
+    assert "encode6_kernel" in kt and nat.last_encode_long_samples() > 0
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=7)
+    rng = np.random.default_rng(5)
+    raw = flat.tobytes()
+    texts = [raw[:k] for k in (0, 1, 15, 16, 17, 63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 4096, 70000)] + [b"", b"", raw[5000:5000 + (1 << 20)]]
+    texts += [raw[int(a):int(a) + int(k)] for a, k in zip(rng.integers(0, 1 << 20, 300), rng.integers(1, 3000, 300))]
+    f2, o2 = tgx.pack(texts)
+    assert_same_encoding(nat, ora, f2, o2)
+    # unreachable ends (no single-byte cover) are reported as by the other kernels
+    sparse = tgx.NativeModel([b"a", b"b", b"ab"], [-1.0, -1.0, -1.5])
+    f3, o3 = tgx.pack([b"ab" * 5000, b"ab" * 3000 + b"c" + b"ab" * 100, b"ba" * 2000])
+    with pytest.raises(tgx.TokenGeeXError) as e:
+        sparse.encode_batch_flat(f3, o3)
+    assert e.value.sample == 1 and str(e.value) == "no path to position 6201/6201"
+
+
+def test_long_sample_threshold_default():
+    """By default the long samples of a batch get a block of their own only where the estimate says the pass gets
+    shorter: the long ones of a 16 MiB batch of samples <= 64 KiB, none of a 64 MiB batch of samples <= 4 KiB."""
+    flat, offs, toks, scores = corpus_and_vocab(16 << 20, "mixed", 4000, 16, seed_offset=52)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    assert_same_encoding(nat, ora, flat, offs)
+    assert 0 < nat.last_encode_long_samples() < offs.size - 1 and "encode6_kernel" in nat.last_kernel_times()
+    f2, o2 = synth.make_corpus(64 << 20, "mixed", max_len=4096, seed_offset=53)
+    res = nat.encode_batch_flat(f2, o2)
+    res.free()
+    assert nat.last_encode_long_samples() == 0 and "encode6_kernel" not in nat.last_kernel_times()

@@ -82,6 +82,7 @@ SYMBOLS = {
     "tgx_last_algorithmic_bytes": (_u64, [_vp]),
     "tgx_last_encode_waves_per_cu": (_u32, [_vp]),
     "tgx_last_encode_redo_samples": (_u64, [_vp]),
+    "tgx_last_encode_long_samples": (_u64, [_vp]),
 }
 
 
@@ -437,6 +438,9 @@ class NativeModel:
 
     def last_encode_redo_samples(self) -> int:
         return lib.tgx_last_encode_redo_samples(self._h)
+
+    def last_encode_long_samples(self) -> int:
+        return lib.tgx_last_encode_long_samples(self._h)
 
 
 class FlatTrie:

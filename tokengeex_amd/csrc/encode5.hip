@@ -297,27 +297,27 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
                 const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
                 sv[u] = *reinterpret_cast<const double*>(smem + a);
             }
-            relax4_step<0>(sv[0], acc, bpv, fin[g], fhi);
-            relax4_step<1>(sv[1], acc, bpv, fin[g], fhi);
-            relax4_step<2>(sv[2], acc, bpv, fin[g], fhi);
-            relax4_step<3>(sv[3], acc, bpv, fin[g], fhi);
-            relax4_step<4>(sv[4], acc, bpv, fin[g], fhi);
-            relax4_step<5>(sv[5], acc, bpv, fin[g], fhi);
-            relax4_step<6>(sv[6], acc, bpv, fin[g], fhi);
-            relax4_step<7>(sv[7], acc, bpv, fin[g], fhi);
+            relax5_step<0>(sv[0], acc, bpv, fin[g], fhi);
+            relax5_step<1>(sv[1], acc, bpv, fin[g], fhi);
+            relax5_step<2>(sv[2], acc, bpv, fin[g], fhi);
+            relax5_step<3>(sv[3], acc, bpv, fin[g], fhi);
+            relax5_step<4>(sv[4], acc, bpv, fin[g], fhi);
+            relax5_step<5>(sv[5], acc, bpv, fin[g], fhi);
+            relax5_step<6>(sv[6], acc, bpv, fin[g], fhi);
+            relax5_step<7>(sv[7], acc, bpv, fin[g], fhi);
 #pragma unroll
             for (int u = 8; u < 16; ++u) {
                 const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
                 sv[u - 8] = *reinterpret_cast<const double*>(smem + a);
             }
-            relax4_step<8>(sv[0], acc, bpv, fin[g], fhi);
-            relax4_step<9>(sv[1], acc, bpv, fin[g], fhi);
-            relax4_step<10>(sv[2], acc, bpv, fin[g], fhi);
-            relax4_step<11>(sv[3], acc, bpv, fin[g], fhi);
-            relax4_step<12>(sv[4], acc, bpv, fin[g], fhi);
-            relax4_step<13>(sv[5], acc, bpv, fin[g], fhi);
-            relax4_step<14>(sv[6], acc, bpv, fin[g], fhi);
-            relax4_step<15>(sv[7], acc, bpv, fin[g], fhi);
+            relax5_step<8>(sv[0], acc, bpv, fin[g], fhi);
+            relax5_step<9>(sv[1], acc, bpv, fin[g], fhi);
+            relax5_step<10>(sv[2], acc, bpv, fin[g], fhi);
+            relax5_step<11>(sv[3], acc, bpv, fin[g], fhi);
+            relax5_step<12>(sv[4], acc, bpv, fin[g], fhi);
+            relax5_step<13>(sv[5], acc, bpv, fin[g], fhi);
+            relax5_step<14>(sv[6], acc, bpv, fin[g], fhi);
+            relax5_step<15>(sv[7], acc, bpv, fin[g], fhi);
             reached[g] = fhi != 0xFFF00000u;
         }
         __builtin_amdgcn_wave_barrier();
@@ -368,6 +368,222 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
     }
 }
 
+// ---- encode6_kernel: long samples ---------------------------------------------------------------------------
+// A sample is a serial chain: in encode5_kernel a row walks 64 positions, relaxes them, walks the next 64, so a
+// 64 KiB sample takes 1024 x (walk + relax) = 8 ms however idle the chip is, and batches of a few hundred MB
+// (the per-GPU shards of the prune and merge passes, a 10 MB batch) are bound by their longest samples.  Only
+// the relaxation is serial — the walks of different positions are independent — so this kernel gives every
+// long sample a whole block: seven WALKER waves fill a ring of match-index buffers (64 positions per trip, the
+// walk of encode5_kernel) ahead of one RELAXER wave, which consumes the trips in order, so the sample's chain is
+// 16 relax steps per 16 positions and nothing else.  Hand-over inside the block through LDS words:
+//   epoch        relaxer -> walkers: a new sample's (index, begin, length, first trip) is published
+//   walk_done[i] walker -> relaxer: ring slot i holds trip (value - 1)
+//   relax_done   relaxer -> walkers: trips consumed so far (slot t % G is free once t < relax_done + G)
+// Trip ids run on across samples, so the words never need resetting.  LDS operations of a wave are performed
+// in order and the LDS is one pipeline per CU, so a flag written after the data is seen after the data.
+// Same back-pointer bytes and status as encode5_kernel (its relaxation, row 0 of the wave), same trace kernel.
+struct E6Ctrl {
+    uint32_t epoch;       // 0 = nothing yet, 0xFFFFFFFF = no more samples
+    uint32_t s, n, trip0;
+    uint64_t beg;
+    uint32_t relax_done;
+    uint32_t pad;
+    uint32_t walk_done[24];
+};
+constexpr uint32_t kE6Done = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <bool DROPOUT>
+__global__ __launch_bounds__(512) void encode6_kernel(EncodeParams P, Encode5Params Q) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t LM = 16;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = lane & 15u, r = lane >> 4;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t K = (blockDim.x >> 6) - 1u, G = Q.ring_slots;
+    const uint2* __restrict__ trie = reinterpret_cast<const uint2*>(Q.trie8);
+    double* const score_tab = reinterpret_cast<double*>(smem);
+    const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
+    E6Ctrl* ctrl = reinterpret_cast<E6Ctrl*>(smem + Q.ctrl_off);
+    {
+        const double ninf_ = -__builtin_huge_val();
+        for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = i ? Q.hot[i - 1u] : ninf_;
+        uint2* rw = reinterpret_cast<uint2*>(smem + Q.root_off);
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
+        uint32_t* cw = reinterpret_cast<uint32_t*>(ctrl);
+        for (uint32_t i = threadIdx.x; i < sizeof(E6Ctrl) / 4u; i += blockDim.x) cw[i] = 0u;
+        __syncthreads();
+    }
+    const double ninf = -__builtin_huge_val();
+
+    if (wave == 0u) {
+        // ================= relaxer =================
+        uint32_t trip0 = 0, epoch = 0;
+        for (;;) {
+            const uint64_t k = wave_fetch_add(P.queue, 1u);
+            if (k >= P.n_samples) {
+                if (lane == 0u) lds_store(&ctrl->epoch, kE6Done);
+                break;
+            }
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
+            const uint64_t beg = first_u64(P.offs[s]);
+            const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
+            const uint32_t n_trips = n / 64u + 1u;
+            if (lane == 0u) {
+                ctrl->s = s;
+                ctrl->n = n;
+                ctrl->beg = beg;
+                ctrl->trip0 = trip0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            epoch++;
+            if (lane == 0u) lds_store(&ctrl->epoch, epoch);
+
+            double acc = (l == 0u) ? 0.0 : ninf;
+            uint32_t bpv = kNoStep;
+            uint32_t pk = 0, pk_j = 0;
+            bool pk_dirty = false;
+            uint8_t* const bpw = P.bp8 + bp8_base(beg, s);
+            uint32_t slot = trip0 % G;
+            for (uint32_t tau = 0; tau < n_trips; ++tau, slot = (slot + 1u == G) ? 0u : slot + 1u) {
+                const uint32_t t = trip0 + tau;
+                while (lds_load(&ctrl->walk_done[slot]) != t + 1u) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint32_t p0 = tau * 64u;
+                const unsigned char* sbase = smem + Q.ring_off + slot * kE5GroupBytes;
+                uint32_t fin[4];
+                bool reached[4];
+                uint32_t pg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    pg[g] = p0 + 16u * g + l;
+                    fin[g] = kNoStep;
+                    // every row of the wave relaxes the same 16 positions (group g of the trip): row 0 counts
+                    const uint4* ip = reinterpret_cast<const uint4*>(sbase + g * kE5RowStride + ((l - 1u) & 15u) * 32u);
+                    const uint4 ia = ip[0], ib = ip[1];
+                    const uint32_t iw[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+                    uint32_t fhi = 0xFFF00000u;
+                    double sv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
+                        sv[u] = *reinterpret_cast<const double*>(smem + a);
+                    }
+                    relax5_step<0>(sv[0], acc, bpv, fin[g], fhi);
+                    relax5_step<1>(sv[1], acc, bpv, fin[g], fhi);
+                    relax5_step<2>(sv[2], acc, bpv, fin[g], fhi);
+                    relax5_step<3>(sv[3], acc, bpv, fin[g], fhi);
+                    relax5_step<4>(sv[4], acc, bpv, fin[g], fhi);
+                    relax5_step<5>(sv[5], acc, bpv, fin[g], fhi);
+                    relax5_step<6>(sv[6], acc, bpv, fin[g], fhi);
+                    relax5_step<7>(sv[7], acc, bpv, fin[g], fhi);
+#pragma unroll
+                    for (int u = 8; u < 16; ++u) {
+                        const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
+                        sv[u - 8] = *reinterpret_cast<const double*>(smem + a);
+                    }
+                    relax5_step<8>(sv[0], acc, bpv, fin[g], fhi);
+                    relax5_step<9>(sv[1], acc, bpv, fin[g], fhi);
+                    relax5_step<10>(sv[2], acc, bpv, fin[g], fhi);
+                    relax5_step<11>(sv[3], acc, bpv, fin[g], fhi);
+                    relax5_step<12>(sv[4], acc, bpv, fin[g], fhi);
+                    relax5_step<13>(sv[5], acc, bpv, fin[g], fhi);
+                    relax5_step<14>(sv[6], acc, bpv, fin[g], fhi);
+                    relax5_step<15>(sv[7], acc, bpv, fin[g], fhi);
+                    reached[g] = fhi != 0xFFF00000u;
+                }
+                // the slot's entries are consumed: its walker-to-be may reset and refill it
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0u) lds_store(&ctrl->relax_done, t + 1u);
+                // back-pointer bytes (encode5_kernel's packed, permuted layout); row 0 stores
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (pg[g] >= 1u && pg[g] <= n) {
+                        const uint32_t b = reached[g] ? ((l - fin[g] - 1u) & 15u) : 0xFFu;
+                        const uint32_t j = pg[g] - 1u, kq = (j >> 4) & 3u;
+                        pk = (kq == 0u) ? b : (pk | (b << (8u * kq)));
+                        pk_j = j;
+                        pk_dirty = true;
+                        if (kq == 3u) {
+                            if (r == 0u) __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(j) & ~3u)));
+                            pk_dirty = false;
+                        }
+                    }
+                const uint32_t left = n - p0;
+                if (left < 64u) {
+                    if (pk_dirty && r == 0u) __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(pk_j) & ~3u)));
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (r == 0u && left == 16u * g + l) P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
+                }
+            }
+            trip0 += n_trips;
+        }
+        return;
+    }
+
+    // ================= walkers =================
+    const uint32_t w = wave - 1u;
+    uint32_t seen = 0;
+    for (;;) {
+        uint32_t e;
+        while ((e = lds_load(&ctrl->epoch)) == seen) __builtin_amdgcn_s_sleep(2);
+        if (e == kE6Done) break;
+        seen = e;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t s = ctrl->s, n = ctrl->n, trip0 = ctrl->trip0;
+        const uint64_t beg = ctrl->beg;
+        const uint32_t n_trips = n / 64u + 1u;
+        const uint32_t tau0 = (w + K - trip0 % K) % K;
+        uint32_t slot = (trip0 + tau0) % G;
+        for (uint32_t tau = tau0; tau < n_trips; tau += K, slot = (slot + K >= G) ? slot + K - G : slot + K) {
+            const uint32_t t = trip0 + tau;
+            while (t >= lds_load(&ctrl->relax_done) + G) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t p0 = tau * 64u, pgl = p0 + lane;
+            // text window of this lane's position
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + beg + pgl);
+            const uint32_t sh = (uint32_t)(addr & 3u);
+            const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
+            uint32_t wv[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) wv[q] = wp[q];
+            uint32_t bytes[1][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bytes[0][q] = __builtin_amdgcn_alignbyte(wv[q + 1], wv[q], sh);
+            // reset this lane's reader column of its group, then walk
+            const uint32_t slot_off = Q.ring_off + slot * kE5GroupBytes;
+            {
+                uint4* mine = reinterpret_cast<uint4*>(smem + slot_off + r * kE5RowStride + ((l - 1u) & 15u) * 32u);
+                mine[0] = make_uint4(0, 0, 0, 0);
+                mine[1] = make_uint4(0, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t pg[1] = {pgl}, maxd[1], wlane[1], c[1];
+            bool alive[1];
+            uint2 rec[1];
+            const uint32_t rem = pgl < n ? (n - pgl) : 0u;
+            maxd[0] = rem < LM ? rem : LM;
+            alive[0] = maxd[0] > 0;
+            wlane[0] = slot_off + r * kE5RowStride + l * 2u;
+            c[0] = bytes[0][0] & 0xFFu;
+            rec[0] = rootc[(Q.root_base ^ c[0]) & 255u];
+            uint32_t pool_cnt = 0;
+            double pend_val[1] = {0.0};
+            uint32_t pend_addr[1] = {0u};
+            bool bad = false;
+            uint32_t l32 = l * 32u;
+            asm volatile("" : "+v"(l32));
+            WalkCtx<1> W{trie, rootc, smem, Q.cold_scores, Q.root_base, 0u, 0u, s, 0u, l32, P.dropout, P.seed};
+            Walk5<DROPOUT, false, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pend_val, pend_addr, pool_cnt, bad);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0u) lds_store(&ctrl->walk_done[slot], t + 1u);
+        }
+    }
+}
+
 typedef void (*encode5_fn)(EncodeParams, Encode5Params);
 static encode5_fn pick_encode5(bool dropout, bool cold, int ppl) {
     if (cold) {
@@ -399,6 +615,29 @@ hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out) {
     const int regs = (attr.numRegs + 7) & ~7;
     *out = regs > 0 ? (512 / regs > 8 ? 8 : 512 / regs) : 8;
     return hipSuccess;
+}
+
+// LDS of an encode6_kernel block: score table, root records, control words, ring of `slots` match-index buffers
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t slots, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
+    const uint32_t score_bytes = 8u * (n_hot + 1u);
+    if (score_bytes > 65536u || slots > 24u) return 0;
+    const uint32_t ro = (score_bytes + 15u) & ~15u;
+    const uint32_t co = ro + 2048u;
+    const uint32_t go = (co + (uint32_t)sizeof(E6Ctrl) + 511u) & ~511u;
+    if (root_off) *root_off = ro;
+    if (ctrl_off) *ctrl_off = co;
+    if (ring_off) *ring_off = go;
+    return go + slots * kE5GroupBytes;
+}
+hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, int walkers, uint32_t blocks, hipStream_t stream) {
+    q.ring_slots = (uint32_t)walkers + 2u;
+    const uint32_t lds = encode6_lds_layout(q.n_hot, q.ring_slots, &q.root_off, &q.ctrl_off, &q.ring_off);
+    if (lds == 0 || lds > 160u * 1024u || walkers < 1 || walkers > 15) return hipErrorInvalidValue;
+    auto fn = p.dropout > 0.0 ? encode6_kernel<true> : encode6_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)(walkers + 1)), lds, stream, p, q);
+    return hipGetLastError();
 }
 
 hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream) {

@@ -41,6 +41,7 @@ struct Encode5Params {
     uint32_t root_base, n_hot;
     uint32_t pool_entries;          // per wave: LDS entries for cold values of one iteration
     uint32_t root_off, idx_off;     // LDS layout (set by the launcher)
+    uint32_t ctrl_off, ring_off, ring_slots;  // encode6_kernel: control words, ring of match-index buffers
     unsigned long long* redo_count; // samples whose wave ran out of pool entries (init 0) ...
     uint32_t* redo_list;            // ... and their indices, u32[S]: encode4_kernel redoes exactly those
 };
@@ -146,6 +147,8 @@ uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 uint32_t encode5_lds_layout(uint32_t n_hot, uint32_t pool_entries, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off);
 hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out);
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t slots, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
+hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, int walkers, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip
 hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream);

@@ -195,6 +195,7 @@ struct tgx_model {
     bool rev_host_built = false;    // flat_rev was built at creation (TGX_MODEL_FOR_ESTEP)
     void* d_trie_w = nullptr;       // forward / reversed tables with w = exp(score) in place of the score
     void* d_trie_rev_w = nullptr;   //   (linear-domain E-step, estep4l.hip)
+    uint64_t last_long_samples = 0;    // samples the last pass gave a block of their own (encode6_kernel)
     uint64_t last_redo_samples = 0;    // samples the last encode4l pass left to encode2_kernel
     int last_encode_waves_per_cu = 0;  // resident waves per CU of the last rows4 encode launch (self-check)
     bool estep_linear_ok = false;   // tables for the linear-domain E-step kernels exist
@@ -218,6 +219,8 @@ struct tgx_corpus {
     int device = 0;
     uint64_t n_samples = 0, n_bytes = 0, max_len = 0;  // max_len: longest sample in bytes
     std::vector<uint64_t> h_offs;
+    std::vector<uint32_t> h_sorted_len;  // sample lengths in the order of d_order (longest first) ...
+    std::vector<uint64_t> h_sorted_cum;  // ... and their running sum
     uint8_t* d_text = nullptr;        // = d_text_alloc + 256 (the backward E-step sweep reads before a position)
     uint8_t* d_text_alloc = nullptr;
     uint64_t* d_offs = nullptr;
@@ -398,6 +401,53 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         q.redo_list = c->d_counts;  // free until the trace writes the token counts
         m->last_redo_samples = 0;
         if (m->has_cold) HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
+        // Long samples first, each with a block of its own (encode6_kernel: seven walker waves ahead of one
+        // relaxing wave), when that shortens the pass.  encode5_kernel takes ~0.104 us per byte of a sample's
+        // serial chain (6.8 ms per 64 KiB) and ~1 s per 88 GB of batch; encode6_kernel ~0.034 us per byte of
+        // chain (2.25 ms per 64 KiB) but only ~25 GB/s once every CU has its blocks (one relaxing wave per block;
+        // profiles/r02: e6_shapes).  The two run one after the other, so the split is chosen among the powers of
+        // two as thresholds by the sum of the two estimates; TGX_LONG_THRESHOLD forces one (0: never).
+        uint64_t n_long = 0;
+        if (!m->has_cold && c->n_samples) {
+            const auto count_ge = [&](uint64_t thr) {  // h_sorted_len descends: the long samples are a prefix of the order
+                return (uint64_t)(std::partition_point(c->h_sorted_len.begin(), c->h_sorted_len.end(),
+                                                       [thr](uint32_t len) { return len >= thr; }) - c->h_sorted_len.begin());
+            };
+            if (const char* e = getenv("TGX_LONG_THRESHOLD")) {
+                const uint64_t thr = (uint64_t)std::max(0ll, atoll(e));
+                if (thr) n_long = count_ge(thr);
+            } else {
+                const double N = (double)c->n_bytes;
+                auto cost = [&](uint64_t k) {  // the k longest samples to encode6_kernel
+                    const double bytes_long = k ? (double)c->h_sorted_cum[k - 1] : 0.0;
+                    const double t6 = k ? std::max((double)c->h_sorted_len[0] * 0.0343e-6, bytes_long / 25e9) + 20e-6 : 0.0;
+                    const double rest_max = k < c->n_samples ? (double)c->h_sorted_len[k] : 0.0;
+                    const double t5 = std::max(rest_max * 0.104e-6, (N - bytes_long) / 88e9);
+                    return t6 + t5;
+                };
+                double best = cost(0);
+                for (uint64_t thr = 1024; thr <= c->max_len; thr *= 2) {
+                    const uint64_t k = count_ge(thr);
+                    const double ck = cost(k);
+                    if (k && ck < best * 0.9) {  // switch for a clear gain only
+                        best = ck;
+                        n_long = k;
+                    }
+                }
+            }
+        }
+        m->last_long_samples = n_long;
+        if (n_long) {
+            tgx::EncodeParams p6 = p;
+            p6.n_samples = n_long;
+            const uint32_t blocks6 = (uint32_t)std::min<uint64_t>(n_long, (uint64_t)m->num_cus * 4);
+            time_begin(m, "encode6_kernel");
+            HIP_TRY(tgx::launch_encode6(p6, q, 7, blocks6, m->stream));
+            time_end(m);
+            HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode5_kernel
+            p.order = c->d_order + n_long;
+            p.n_samples = c->n_samples - n_long;
+        }
         unsigned long long* d_stamps5 = nullptr;
         const size_t n_stamp_waves5 = (size_t)blocks5 * (size_t)waves;
         if (const char* e = getenv("TGX_STAMPS")) {
@@ -441,6 +491,8 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 time_end(m);
             }
         }
+        p.order = c->d_order;
+        p.n_samples = c->n_samples;
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
         time_begin(m, "trace_kernel");
@@ -951,6 +1003,13 @@ tgx_status tgx_corpus_upload(int device, const uint8_t* text, const uint64_t* of
     });
 
     c->max_len = n_samples ? ho[order[0] + 1] - ho[order[0]] : 0;
+    c->h_sorted_len.resize(n_samples);
+    c->h_sorted_cum.resize(n_samples);
+    for (uint64_t i = 0, run = 0; i < n_samples; i++) {
+        c->h_sorted_len[i] = (uint32_t)(ho[order[i] + 1] - ho[order[i]]);
+        run += c->h_sorted_len[i];
+        c->h_sorted_cum[i] = run;
+    }
     auto cleanup = [&](tgx_status st) {
         tgx_corpus_free(c);
         return st;
@@ -1808,5 +1867,6 @@ int tgx_last_kernel_times(const tgx_model* m, const char** names, float* ms, int
 uint32_t tgx_last_encode_waves_per_cu(const tgx_model* m) { return m ? (uint32_t)m->last_encode_waves_per_cu : 0u; }
 uint64_t tgx_last_algorithmic_bytes(const tgx_model* m) { return m ? m->last_alg_bytes : 0; }
 uint64_t tgx_last_encode_redo_samples(const tgx_model* m) { return m ? m->last_redo_samples : 0; }
+uint64_t tgx_last_encode_long_samples(const tgx_model* m) { return m ? m->last_long_samples : 0; }
 
 }  // extern "C"
