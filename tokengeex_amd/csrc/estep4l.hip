@@ -56,12 +56,17 @@ __device__ __forceinline__ void e4l_fwd_step(double sv, double& acc, double& fin
 }
 
 // Hot slots (P.n_hot): expected counts of the first (hottest-first order) slots of the reversed trie are summed in
-// the block's LDS and flushed once at the end; 2048 slots take about three quarters of all matches, and
-// the global f64 atomics (executed at the memory side, not in L2) are what bounds the backward kernel.
+// the block's LDS and flushed once at the end; the global f64 atomics of the others (executed at the memory
+// side, not in L2: ~30 G scattered adds per second chip-wide whatever their locality — 888 M of them per GiB
+// with 2048 hot slots, TCC_EA0_ATOMIC in profiles/r02/t_passes_1GiB) are what bounds the backward kernel.
+// So the LDS goes to the hot set: a hot entry is {sum, w = exp(score)} and the match buffer holds the SLOT of a
+// match only (4 bytes per (position, length) instead of 12: the weight is read from the hot entry, or from the
+// trie record in HBM for a cold slot), which leaves room for 7 000 hot slots instead of 2 000.
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
 template <int U>
 __device__ __forceinline__ void e4l_bwd_step(double sv, uint32_t hv, double c_cur, double c_nxt, int e_cur, int e_nxt,
-                                             int eb, double* __restrict__ expected_slot, double* hot, uint32_t n_hot, bool cold_ok, double& acc) {
+                                             int eb, double* __restrict__ expected_slot, double2* hot, uint32_t n_hot, bool cold_ok, double& acc) {
     constexpr uint64_t MU = kRowLane0 << U;
     constexpr uint64_t WRAPPED = (uint64_t)((1u << (U + 1)) - 1u) * kRowLane0;  // lanes l <= U: position y0 + 16 + l
     const double best = row_bcast_f64<U>(acc);  // b[q] of the source (end) position
@@ -71,7 +76,7 @@ __device__ __forceinline__ void e4l_bwd_step(double sv, uint32_t hv, double c_cu
     if (sv != 0.0) {  // lattice.rs:305-307
         const double mg = ldexp(cand * c, e + eb);
         if (hv < n_hot)
-            atomicAdd(&hot[hv], mg);  // ds_add_f64
+            atomicAdd(&hot[hv].x, mg);  // ds_add_f64
         else if (cold_ok)
             atomicAdd(&expected_slot[hv], mg);
     }
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
 }
 
 template <bool DROPOUT, int PPL>
-__global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
+__global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
     constexpr uint32_t SPAN = 16u * PPL;
@@ -256,16 +261,16 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie_rev);  // records carry w = exp(score)
-    double* hot = reinterpret_cast<double*>(smem);  // kHotSlots partial sums, shared by the block
-    const uint32_t n_hot = P.n_hot;  // slots summed in LDS (wave-uniform)
-    unsigned char* wbase = smem + n_hot * 8u + (size_t)wave * (PPL * kE4LEntries * 12u);
-    double* sc = reinterpret_cast<double*>(wbase);                               // PPL groups of scores
-    uint32_t* hl = reinterpret_cast<uint32_t*>(wbase + PPL * kE4LEntries * 8u);  // PPL groups of slots
+    double2* hot = reinterpret_cast<double2*>(smem);  // n_hot + 1 entries {partial sum, w}, shared by the block
+    const uint32_t n_hot = P.n_hot;  // slots summed in LDS (wave-uniform); entry n_hot is {0, 0}: "no token"
+    unsigned char* wbase = smem + (n_hot + 1u) * 16u + (size_t)wave * (PPL * kE4LEntries * 4u);
+    uint32_t* hl = reinterpret_cast<uint32_t*>(wbase);  // PPL groups of slots
     // expected counts go to one of n_replicas copies of the slot array (reduced afterwards):
     // a handful of very frequent tokens would otherwise serialise every wave's atomics
     double* __restrict__ expected_slot = P.expected_slot + (size_t)(blockIdx.x % P.n_replicas) * P.n_slots_rev;
     const bool cold_ok = (P.flags & 8u) == 0u;
-    for (uint32_t i = threadIdx.x; i < n_hot; i += blockDim.x) hot[i] = 0.0;
+    for (uint32_t i = threadIdx.x; i <= n_hot; i += blockDim.x)
+        hot[i] = make_double2(0.0, (i < n_hot && i < P.n_slots_rev) ? reinterpret_cast<const double*>(P.trie_rev)[2u * i + 1u] : 0.0);
     __syncthreads();
 
     uint32_t s = 0, n = 0, y0 = 0, smp = 0;
@@ -349,9 +354,9 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
                 bytes[g][j] = __builtin_amdgcn_alignbyte(w[4 * (PPL - 1 - g) + j + 1], w[4 * (PPL - 1 - g) + j], sh);
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
-            double2* grp = reinterpret_cast<double2*>(sc + g * kE4LEntries);
+            uint4* grp = reinterpret_cast<uint4*>(hl + g * kE4LEntries);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) grp[j * 64 + lane] = make_double2(0.0, 0.0);
+            for (int j = 0; j < 4; ++j) grp[j * 64 + lane] = make_uint4(kNoSlot, kNoSlot, kNoSlot, kNoSlot);
         }
 #pragma unroll
         for (int d = 0; d < (int)LM; ++d) {
@@ -384,11 +389,7 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
                             if (term && d >= 1)
                                 term = !(dropout_u01(P.seed, smp, sbase + (uint64_t)(qq[g] - (uint32_t)d - 1u), (uint32_t)d + 1u) < P.dropout);
                         }
-                        if (term) {
-                            const uint32_t col = ((uint32_t)d + l) & 15u;
-                            (sc + g * kE4LEntries + lane * LM)[col] = __hiloint2double((int)rec[g].w, (int)rec[g].z);
-                            (hl + g * kE4LEntries + lane * LM)[col] = t[g];
-                        }
+                        if (term) (hl + g * kE4LEntries + lane * LM)[((uint32_t)d + l) & 15u] = t[g];
                     }
                 }
             }
@@ -398,29 +399,35 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
         // ---- backward recursion + marginals: 16 static steps per group, then the row is rescaled
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
-            const double* scr = sc + g * kE4LEntries + r * 256u + ((l - 1u) & 15u);
             const uint32_t* hlr = hl + g * kE4LEntries + r * 256u + ((l - 1u) & 15u);
             const double c_cur = cfw[g], c_nxt = cfw[g + 1];
             const int e_cur = efw[g], e_nxt = efw[g + 1];
+            uint32_t hvs[16];
             double sv[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) sv[u] = scr[u * 16];
-            e4l_bwd_step<0>(sv[0], hlr[0 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<1>(sv[1], hlr[1 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<2>(sv[2], hlr[2 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<3>(sv[3], hlr[3 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<4>(sv[4], hlr[4 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<5>(sv[5], hlr[5 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<6>(sv[6], hlr[6 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<7>(sv[7], hlr[7 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<8>(sv[8], hlr[8 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<9>(sv[9], hlr[9 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<10>(sv[10], hlr[10 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<11>(sv[11], hlr[11 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<12>(sv[12], hlr[12 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<13>(sv[13], hlr[13 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<14>(sv[14], hlr[14 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<15>(sv[15], hlr[15 * 16], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            for (int u = 0; u < 16; ++u) hvs[u] = hlr[u * 16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {  // w of the match: hot entry (entry n_hot = 0.0 for "no token") ...
+                sv[u] = hot[hvs[u] < n_hot ? hvs[u] : n_hot].y;
+                // ... or, for a slot outside the hot set, the trie record in HBM
+                if (hvs[u] != kNoSlot && hvs[u] >= n_hot) sv[u] = reinterpret_cast<const double*>(P.trie_rev)[2u * hvs[u] + 1u];
+            }
+            e4l_bwd_step<0>(sv[0], hvs[0], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<1>(sv[1], hvs[1], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<2>(sv[2], hvs[2], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<3>(sv[3], hvs[3], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<4>(sv[4], hvs[4], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<5>(sv[5], hvs[5], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<6>(sv[6], hvs[6], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<7>(sv[7], hvs[7], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<8>(sv[8], hvs[8], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<9>(sv[9], hvs[9], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<10>(sv[10], hvs[10], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<11>(sv[11], hvs[11], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<12>(sv[12], hvs[12], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<13>(sv[13], hvs[13], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<14>(sv[14], hvs[14], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            e4l_bwd_step<15>(sv[15], hvs[15], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
             const int e = row_max_exponent(acc);
             if (e > -100000) {
                 acc = ldexp(acc, -e);
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(768) void estep4l_bwd_kernel(Estep4Params P) {
     __syncthreads();
     const uint32_t n_flush = P.n_slots_rev < n_hot ? P.n_slots_rev : n_hot;
     for (uint32_t i = threadIdx.x; i < n_flush; i += blockDim.x) {
-        const double v = hot[i];
+        const double v = hot[i].x;
         if (v != 0.0) atomicAdd(&expected_slot[i], v);
     }
 }
@@ -483,24 +490,23 @@ hipError_t launch_estep4l_fwd(const Estep4Params& p, int ppl, uint32_t num_cus, 
                        stream, p);
     return hipGetLastError();
 }
-// backward: ONE block per CU: 12 / 6 / 3 waves x 12 KiB * ppl of match buffers + 16 KiB of hot-slot sums = 160 KiB
+// backward: ONE block per CU: 16 / 8 / 4 waves x 4 KiB * ppl of match buffers (slots), the rest of the 160 KiB hot entries
 hipError_t launch_estep4l_bwd(const Estep4Params& p0, int ppl, uint32_t num_cus, hipStream_t stream) {
-    // groups of 16 positions per block: 12 (x 12 KiB of match buffer) leave 16 KiB = 2048 hot slots; fewer
-    // groups, more slots summed in LDS instead of memory-side atomics (about 30 G scattered f64 adds per second
-    // chip-wide, whatever their locality).  With 2 positions per lane — picked for passes bound by the serial
-    // chain of their longest snippets, where waves are not what is missing — 8 groups and 8192 slots:
-    // 23.2 -> 20.9 ms per 256 MiB (tools/bwd_groups_sweep.py; TGX_BWD_GROUPS overrides).
-    uint32_t groups = ppl == 2 ? 8 : 12;
+    // groups of 16 positions per block: 16 (x 4 KiB of match buffer) leave 96 KiB = 6 143 hot entries of 16
+    // bytes; fewer groups, more slots summed in LDS instead of by memory-side atomics but fewer waves to hide
+    // the gathers: 44.3 / 40.9 / 39.5 ms per GiB with 12 / 14 / 16 groups, 51.0 ms with the 12 groups and
+    // 2 048 hot slots that 12-byte match entries allowed (profiles/r02; TGX_BWD_GROUPS overrides)
+    uint32_t groups = 16;
     if (const char* e = getenv("TGX_BWD_GROUPS")) {
         const int v = atoi(e);
-        if (v >= 4 && v <= 12) groups = (uint32_t)v;
+        if (v >= 4 && v <= 16) groups = (uint32_t)v;
     }
     Estep4Params p = p0;
     const uint32_t waves = std::max(1u, groups / (uint32_t)ppl);
-    p.n_hot = (160u * 1024u - waves * (uint32_t)ppl * kE4LEntries * 12u) / 8u;
+    p.n_hot = (160u * 1024u - waves * (uint32_t)ppl * kE4LEntries * 4u) / 16u - 1u;
     const uint64_t want = (p.n_snips + 4 * waves - 1) / (4 * waves);
     const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus ? (want ? want : 1) : (uint64_t)num_cus);
-    const uint32_t lds = p.n_hot * 8u + waves * (uint32_t)ppl * kE4LEntries * 12u;
+    const uint32_t lds = (p.n_hot + 1u) * 16u + waves * (uint32_t)ppl * kE4LEntries * 4u;
     hipLaunchKernelGGL(pick_bwd(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * waves), lds, stream, p);
     return hipGetLastError();
 }
