@@ -122,6 +122,17 @@ __device__ __forceinline__ uint64_t claim_rows(unsigned long long* queue, bool n
     return k;
 }
 
+// The same with `chunk` consecutive indices per claiming row: returns the first, the row hands out the rest itself
+__device__ __forceinline__ uint64_t claim_rows_chunk(unsigned long long* queue, bool need_new, uint32_t r, uint32_t chunk) {
+    const uint64_t want = __builtin_amdgcn_ballot_w64(need_new) & kRowLane0;
+    uint64_t k = ~0ull;
+    if (want != 0) {  // wave-uniform
+        const uint64_t base = wave_fetch_add(queue, (uint32_t)__builtin_popcountll(want) * chunk);
+        if (need_new) k = base + (uint64_t)__builtin_popcountll(want & ((1ull << (r * 16u)) - 1ull)) * chunk;
+    }
+    return k;
+}
+
 // One 16-byte trie record in ONE load: the empty asm makes all four words live at
 // once (otherwise the compiler splits the load into three dependent round trips).
 __device__ __forceinline__ uint4 load_rec(const uint4* __restrict__ trie, uint32_t t) {

@@ -180,9 +180,18 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
     uint64_t t_last = P.stamps ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
     uint32_t iters = 0;
 
+    uint64_t local_next = 0, local_end = 0;  // sample indices this row has claimed and not started yet
     for (;;) {
         {
-            const uint64_t k = claim_rows(P.queue, need_new, r);
+            uint64_t k = ~0ull;
+            const bool have_local = need_new && local_next < local_end;
+            if (have_local) k = local_next++;
+            const uint64_t kc = claim_rows_chunk(P.queue, need_new && !have_local, r, Q.claim_chunk);
+            if (need_new && !have_local) {
+                k = kc;
+                local_next = kc + 1u;
+                local_end = kc + Q.claim_chunk;
+            }
             if (need_new) {
                 live = k < P.n_samples;
                 if (live) {

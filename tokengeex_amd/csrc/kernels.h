@@ -40,6 +40,7 @@ struct Encode5Params {
     const double* hot;              // f64[n_hot]: the table's values, entry i at LDS byte offset 8 (i + 1)
     uint32_t root_base, n_hot;
     uint32_t pool_entries;          // per wave: LDS entries for cold values of one iteration
+    uint32_t claim_chunk;           // consecutive samples of the order a row claims per atomic (>= 1)
     uint32_t root_off, idx_off;     // LDS layout (set by the launcher)
     uint32_t ctrl_off, ring_off, ring_slots;  // encode6_kernel: control words, ring of match-index buffers
     unsigned long long* redo_count; // samples whose wave ran out of pool entries (init 0) ...
@@ -153,7 +154,8 @@ hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int
 hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip
 hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream);
 hipError_t launch_encode4l(const EncodeParams& p, uint32_t num_cus, hipStream_t stream);  // encode4l.hip
-hipError_t launch_scan(const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t stream);
+hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t launch_scan(uint32_t* counts, uint64_t* offsets, uint64_t n, void* temp, size_t temp_bytes, hipStream_t stream);
 hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);
 
 }  // namespace tgx

@@ -229,6 +229,8 @@ struct tgx_corpus {
     uint32_t* d_tmp = nullptr;
     uint32_t* d_counts = nullptr;
     uint32_t* d_status = nullptr;
+    void* d_scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
     // the scratch above belongs to the corpus, so a pass holds this lock too (always after its model's):
     // two models may work on one resident corpus from two host threads (prune and merge do, src/prune.rs:48)
     std::mutex mu;
@@ -399,6 +401,12 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         q.pool_entries = m->has_cold ? kE5PoolEntries : 0u;  // no pools for a vocabulary whose values all fit the table
         q.redo_count = m->d_ctrl + 6;
         q.redo_list = c->d_counts;  // free until the trace writes the token counts
+        {   // rows claim several consecutive samples of the order per atomic when samples are short: one global
+            // atomic round trip (~1-2 us) per sample is what a corpus of 130-byte samples otherwise waits for
+            const uint64_t avg = c->n_samples ? c->n_bytes / c->n_samples : 0;
+            q.claim_chunk = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, 4096 / std::max<uint64_t>(1, avg)));
+            if (const char* e = getenv("TGX_CLAIM_CHUNK")) q.claim_chunk = (uint32_t)std::min(64, std::max(1, atoi(e)));
+        }
         m->last_redo_samples = 0;
         if (m->has_cold) HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
         // Long samples first, each with a block of its own (encode6_kernel: seven walker waves ahead of one
@@ -1045,6 +1053,7 @@ void tgx_corpus_free(tgx_corpus* c) {
     pool_free(c->device, c->d_tmp, (size_t)c->n_bytes * 4 + 256);
     pool_free(c->device, c->d_counts, (size_t)c->n_samples * 4 + 256);
     pool_free(c->device, c->d_status, (size_t)c->n_samples * 4 + 256);
+    pool_free(c->device, c->d_scan_tmp, c->scan_tmp_bytes);
     delete c;
 }
 
@@ -1072,8 +1081,14 @@ static tgx_status encode_corpus_locked(tgx_model* m, tgx_corpus* c, double dropo
 
     tgx_status st = run_encode_kernel(m, c, dropout, seed);
     if (st != TGX_OK) return cleanup(st);
+    if (!c->d_scan_tmp) {  // scratch of the device-wide scan (large sample counts only), kept on the corpus
+        if (tgx::scan_temp_bytes(S, &c->scan_tmp_bytes) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "scan temp-size query failed"));
+        if (c->scan_tmp_bytes && pool_alloc(m->device, c->scan_tmp_bytes, &c->d_scan_tmp) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (scan)"));
+    }
     time_begin(m, "scan_counts_kernel");
-    if (tgx::launch_scan(c->d_counts, r->d_offs, S, m->stream) != hipSuccess)
+    if (tgx::launch_scan(c->d_counts, r->d_offs, S, c->d_scan_tmp, c->scan_tmp_bytes, m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "scan launch failed"));
     time_end(m);
     if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
