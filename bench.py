@@ -160,7 +160,8 @@ def main() -> None:
         if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length, args.max_sample_len) == (1024, 32000, "mixed", 16, 65536):
             with open(tpath) as f:
                 tj = json.load(f)
-            if set(tj.get("kernels", {})) == {k.split("<")[0] for k in per_step}:  # same kernel sequence as this build
+            enc = lambda names: {k.split("<")[0] for k in names if k.startswith("encode")}
+            if enc(tj.get("kernels", {})) == enc(per_step):  # same encode kernels as this build
                 traffic = tj.get("hbm_bytes_per_pass_corrected")
                 traffic_source = f"profiles/r02/pmc_traffic.json ({tj.get('commit', '?')})"
         out = {

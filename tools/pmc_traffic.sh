@@ -1,15 +1,15 @@
 #!/bin/bash
 # HBM traffic of the bench kernels: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md),
-# --pmc with --kernel-trace only.  usage: tools/pmc_traffic.sh <outdir-under-gpurun_out>
+# --pmc with --kernel-trace only.  usage: tools/pmc_traffic.sh <outdir-under-gpurun_out> [commit-label]
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1
 mkdir -p $OUT
 cd /tmp
 for P in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 200 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/$P -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/$P.log 2>&1 || { echo "$P failed: stopping"; exit 1; }
+  timeout -k 10 200 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/$P -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > $OUT/$P.log 2>&1 || { echo "$P failed: stopping"; exit 1; }
 done
-python3 - $OUT <<'PY'
+python3 - $OUT ${2:-?} <<'PY'
 import csv, glob, collections, json, sys
 out = sys.argv[1]
 res = collections.defaultdict(dict)
@@ -27,6 +27,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 # 16-B-per-lane stores, partial lines are counted as whole requests
 for k, v in res.items():
     v["hbm_bytes_per_launch_corrected"] = 2 * 1024 * v.get("FETCH_SIZE_KB_per_launch", 0) + 1024 * v.get("WRITE_SIZE_KB_per_launch", 0)
-json.dump({k: v for k, v in res.items() if k.startswith(("encode", "trace", "compact", "scan"))}, open(out + "/traffic.json", "w"), indent=1)
-print(open(out + "/traffic.json").read())
+kern = {k: v for k, v in res.items() if k.startswith(("encode", "trace", "compact", "scan"))}
+doc = {"workload": "bench.py defaults (1 GiB mixed, 32 000-entry vocabulary), --steps 1 --warmup 1 --no-e2e",
+       "commit": sys.argv[2] if len(sys.argv) > 2 else "?",
+       "kernels": kern,
+       "hbm_bytes_per_pass_corrected": sum(v["hbm_bytes_per_launch_corrected"] for v in kern.values())}
+json.dump(doc, open(out + "/pmc_traffic.json", "w"), indent=1)
+print(open(out + "/pmc_traffic.json").read())
 PY
