@@ -35,6 +35,9 @@ def main() -> None:
     ap.add_argument("--max-token-length", type=int, default=16)
     ap.add_argument("--kind", default="mixed", choices=["mixed", "ascii"])
     ap.add_argument("--max-sample-len", type=int, default=65536, help="longest sample of the synthetic corpus, bytes")
+    ap.add_argument("--distinct-scores", action="store_true",
+                    help="give every token its own score (as after an M-step; the default vocabulary scores tokens by "
+                         "integer counts and has ~2 000 distinct values)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive tgx_encode_batch measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
@@ -90,6 +93,8 @@ def main() -> None:
     t0 = time.time()
     vflat, _ = synth.make_corpus(4 << 20, args.kind, seed_offset=0)
     toks, scores = synth.build_vocab(vflat[: 2 << 20], args.vocab, args.max_token_length)
+    if args.distinct_scores:
+        scores = np.asarray(scores, np.float64) + np.random.default_rng(5).uniform(-0.4, 0.4, len(toks))
     flat, offs = synth.make_corpus(args.size_mb << 20, args.kind, max_len=args.max_sample_len, seed_offset=1000 + rank)
     n_bytes, n_samples = int(flat.size), int(offs.size - 1)
     model = tgx.NativeModel(toks, scores, device=dev)
@@ -157,7 +162,7 @@ def main() -> None:
         # named, and only for the workload it was taken on; null otherwise
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-        if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length, args.max_sample_len) == (1024, 32000, "mixed", 16, 65536):
+        if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length, args.max_sample_len, args.distinct_scores) == (1024, 32000, "mixed", 16, 65536, False):
             with open(tpath) as f:
                 tj = json.load(f)
             enc = lambda names: {k.split("<")[0] for k in names if k.startswith("encode")}
@@ -179,6 +184,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"encode_ordinary_batch, {args.vocab} vocab (max token {args.max_token_length} B), "
+                            f"{'every token its own score, ' if args.distinct_scores else ''}"
                             f"{args.size_mb} MiB {args.kind} corpus per GPU (samples <= {args.max_sample_len} B), "
                             f"ids bit-exact vs CPU oracle",
                 "bytes_per_gpu": n_bytes, "samples_per_gpu": n_samples, "tokens_per_gpu": int(n_tokens),

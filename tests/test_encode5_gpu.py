@@ -45,6 +45,7 @@ def test_pool_overflow_redoes_only_the_samples_concerned(monkeypatch):
     scores = _distinct_scores(scores, rng)
     monkeypatch.setenv("TGX_PATH", "rows5")
     monkeypatch.setenv("TGX_E5_MAX_HOT", "8")
+    monkeypatch.setenv("TGX_E5_POOL", "64")  # the default geometry gives a wave as many entries as LDS allows
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
     assert_same_encoding(nat, ora, flat, offs)
     kt = nat.last_kernel_times()
@@ -52,6 +53,7 @@ def test_pool_overflow_redoes_only_the_samples_concerned(monkeypatch):
     assert nat.last_encode_redo_samples() > 0
     assert_same_encoding(nat, ora, flat, offs, dropout=0.4, seed=9)
     monkeypatch.delenv("TGX_E5_MAX_HOT")
+    monkeypatch.delenv("TGX_E5_POOL")
     nat2 = tgx.NativeModel(toks, scores)
     assert_same_encoding(nat2, ora, flat, offs)
     assert "encode4_kernel" not in nat2.last_kernel_times() and nat2.last_encode_redo_samples() == 0
@@ -122,6 +124,38 @@ def test_long_sample_kernel_walkers_and_relaxer(monkeypatch, threshold):
     with pytest.raises(tgx.TokenGeeXError) as e:
         sparse.encode_batch_flat(f3, o3)
     assert e.value.sample == 1 and str(e.value) == "no path to position 6201/6201"
+
+
+@pytest.mark.parametrize("max_hot,pool", [("2000", None), ("300", None), ("40", "16")])
+def test_long_sample_kernel_with_cold_values(monkeypatch, max_hot, pool):
+    """encode6_kernel's walkers with score values outside the table: each ring slot has a pool, filled after the
+    walk in one batch of loads; a slot that runs out flags the sample, which the redo pass encodes."""
+    rng = np.random.default_rng(21)
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 8000, 16, seed_offset=54, max_len=30000)
+    scores = _distinct_scores(scores, rng)
+    monkeypatch.setenv("TGX_PATH", "rows5")
+    monkeypatch.setenv("TGX_E5_MAX_HOT", max_hot)
+    monkeypatch.setenv("TGX_LONG_THRESHOLD", "2000")
+    if pool:
+        monkeypatch.setenv("TGX_E5_POOL", pool)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    assert_same_encoding(nat, ora, flat, offs)
+    kt = nat.last_kernel_times()
+    assert "encode6_kernel" in kt and "encode5_kernel" in kt and nat.last_encode_long_samples() > 0
+    if pool:
+        assert nat.last_encode_redo_samples() > 0 and "encode4_kernel" in kt
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=11)
+
+
+def test_vocabulary_with_distinct_scores_takes_encode4_by_default():
+    """After an M-step every token has its own score (src/prune.rs:143-151): more values than the LDS table holds.
+    Such a model runs encode4_kernel (16-byte records, f64 scores in the match buffer) unless forced."""
+    rng = np.random.default_rng(22)
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 12000, 16, seed_offset=55)
+    nat, ora = tgx.NativeModel(toks, _distinct_scores(scores, rng)), orc.OracleModel(toks, _distinct_scores(scores, np.random.default_rng(22)))
+    assert_same_encoding(nat, ora, flat, offs)
+    kt = nat.last_kernel_times()
+    assert "encode4_kernel" in kt and "encode5_kernel" not in kt and nat.last_encode_redo_samples() == 0
 
 
 def test_long_sample_threshold_default():

@@ -62,23 +62,37 @@ struct WalkCtx {
 // not exist — and the stagger would be lost.  For the same reason the hottest slots are NOT read from an LDS
 // copy: tried, 2 % at best, a step still waits for its slowest lane, which goes to L2.)
 
+// pool entries [0, cnt) hold trie slots (low dword): overwrite each with cold_scores[slot], four batches of 64
+// loads in flight at a time
+__device__ __forceinline__ void fetch_cold_scores(unsigned char* pool, uint32_t cnt, uint32_t lane, const double* __restrict__ cold_scores) {
+    for (uint32_t e0 = 0; e0 < cnt; e0 += 256u) {
+        uint32_t slot[4];
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = e0 + 64u * k + lane;
+            slot[k] = e < cnt ? *reinterpret_cast<const uint32_t*>(pool + e * 8u) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = cold_scores[slot[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = e0 + 64u * k + lane;
+            if (e < cnt) *reinterpret_cast<double*>(pool + e * 8u) = v[k];
+        }
+    }
+}
+
 template <bool DROPOUT, bool COLD, int PPL, int D>
 struct Walk5 {
     // rec[g], c[g]: record and text byte of depth D of walk g (the load may still be in flight)
     static __device__ __forceinline__ void run(const WalkCtx<PPL>& W, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
                                                const uint32_t (&pg)[PPL], const uint32_t (&wlane)[PPL], bool (&alive)[PPL],
-                                               uint2 (&rec)[PPL], uint32_t (&c)[PPL], double (&pend_val)[PPL],
-                                               uint32_t (&pend_addr)[PPL], uint32_t& pool_cnt, bool& bad) {
+                                               uint2 (&rec)[PPL], uint32_t (&c)[PPL], uint32_t& pool_cnt) {
         constexpr int d = D;
         bool any = false;
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
-            if (COLD) {  // a cold score requested one level up came in ahead of this walk's record
-                if (pend_addr[g]) {
-                    *reinterpret_cast<double*>(W.smem + pend_addr[g]) = pend_val[g];
-                    pend_addr[g] = 0u;
-                }
-            }
             alive[g] = alive[g] && ((rec[g].x & 0xFFu) == c[g]);
             bool term = alive[g] && (int32_t)rec[g].y < 0;
             const uint32_t base = rec[g].x >> 8;
@@ -94,15 +108,14 @@ struct Walk5 {
                     const uint32_t e = pool_cnt + rank;
                     pool_cnt += (uint32_t)__builtin_popcountll(cm);
                     if (cold) {
-                        if (e < W.pool_entries) {
-                            pend_val[g] = W.cold_scores[ref & 0x3FFFFFFFu];
-                            pend_addr[g] = W.pool_off + e * 8u;
-                            ref = pend_addr[g];
+                        if (e < W.pool_entries) {  // the entry holds the SLOT for now: fetch_cold_scores() after the walk
+                            const uint32_t at = W.pool_off + e * 8u;
+                            *reinterpret_cast<uint32_t*>(W.smem + at) = ref & 0x3FFFFFFFu;
+                            ref = at;
                         } else {
-                            ref = 0u;  // dropped: the sample is redone
+                            ref = 0u;  // dropped: pool_cnt > pool_entries, the samples of this wave are redone
                         }
                     }
-                    if (pool_cnt > W.pool_entries) bad = true;  // every row of the wave: their samples share the pool
                 }
             }
             if (term) *reinterpret_cast<uint16_t*>(W.smem + (wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u))) = (uint16_t)ref;
@@ -118,14 +131,14 @@ struct Walk5 {
             any = any || alive[g];
         }
         if (__builtin_amdgcn_ballot_w64(any) == 0) return;
-        Walk5<DROPOUT, COLD, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pend_val, pend_addr, pool_cnt, bad);
+        Walk5<DROPOUT, COLD, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pool_cnt);
     }
 };
 template <bool DROPOUT, bool COLD, int PPL>
 struct Walk5<DROPOUT, COLD, PPL, 16> {
     static __device__ __forceinline__ void run(const WalkCtx<PPL>&, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL],
                                                const uint32_t (&)[PPL], const uint32_t (&)[PPL], bool (&)[PPL], uint2 (&)[PPL],
-                                               uint32_t (&)[PPL], double (&)[PPL], uint32_t (&)[PPL], uint32_t&, bool&) {}
+                                               uint32_t (&)[PPL], uint32_t&) {}
 };
 
 // TGX_STAMPS=1 (diagnostic runs only): s_memtime stamps around the phases of an iteration, summed per wave
@@ -259,27 +272,23 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             rec[g] = rootc[(Q.root_base ^ c[g]) & 255u];
         }
         uint32_t pool_cnt = 0;          // wave-uniform: pool entries handed out in this iteration
-        double pend_val[PPL];           // cold scores on their way from HBM ...
-        uint32_t pend_addr[PPL];        // ... and the pool entries they go to (0 = none)
-#pragma unroll
-        for (int g = 0; g < PPL; ++g) {
-            pend_val[g] = 0.0;
-            pend_addr[g] = 0u;
-        }
         {
             // (opaque per trip: as a loop invariant the sixteen column offsets of a lane get hoisted out of the
             // sample loop, kept in registers and spilled)
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
             WalkCtx<PPL> W{trie, rootc, smem, Q.cold_scores, Q.root_base, Q.pool_entries, pool_off, s, P.flags, l32, P.dropout, P.seed};
-            Walk5<DROPOUT, COLD, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pend_val, pend_addr, pool_cnt, bad);
-        }
-        if (COLD) {
-#pragma unroll
-            for (int g = 0; g < PPL; ++g)
-                if (pend_addr[g]) *reinterpret_cast<double*>(smem + pend_addr[g]) = pend_val[g];
+            Walk5<DROPOUT, COLD, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pool_cnt);
         }
         __builtin_amdgcn_wave_barrier();
+        if (COLD) {
+            // the cold matches of this iteration left their slots in the pool: replace them by the scores, all loads
+            // of the batch in flight together (a load issued inside the walk, on some paths only, costs the walks
+            // their stagger: the compiler then waits for every outstanding load at every use)
+            if (pool_cnt > Q.pool_entries) bad = true;  // every row of the wave: their samples share the pool
+            fetch_cold_scores(smem + pool_off, pool_cnt < Q.pool_entries ? pool_cnt : Q.pool_entries, lane, Q.cold_scores);
+            __builtin_amdgcn_wave_barrier();
+        }
         E5_STAMP(2)  // walk
         {   // the following block's text window lands while the relax runs
             const uint32_t* __restrict__ np = wp + 4 * PPL;
@@ -396,7 +405,7 @@ struct E6Ctrl {
     uint32_t s, n, trip0;
     uint64_t beg;
     uint32_t relax_done;
-    uint32_t pad;
+    uint32_t bad;         // COLD: a walker of the current sample ran out of pool entries (the sample is redone)
     uint32_t walk_done[24];
 };
 constexpr uint32_t kE6Done = 0xFFFFFFFFu;
@@ -404,7 +413,7 @@ constexpr uint32_t kE6Done = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <bool DROPOUT>
+template <bool DROPOUT, bool COLD>
 __global__ __launch_bounds__(512) void encode6_kernel(EncodeParams P, Encode5Params Q) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
@@ -528,6 +537,15 @@ __global__ __launch_bounds__(512) void encode6_kernel(EncodeParams P, Encode5Par
                         if (r == 0u && left == 16u * g + l) P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
                 }
             }
+            if (COLD) {  // every walker of this sample has published its last trip (acquired above)
+                if (lds_load(&ctrl->bad) != 0u) {
+                    if (lane == 0u) {
+                        const unsigned long long at = atomicAdd(Q.redo_count, 1ull);
+                        Q.redo_list[at] = s;
+                        lds_store(&ctrl->bad, 0u);
+                    }
+                }
+            }
             trip0 += n_trips;
         }
         return;
@@ -580,13 +598,16 @@ __global__ __launch_bounds__(512) void encode6_kernel(EncodeParams P, Encode5Par
             c[0] = bytes[0][0] & 0xFFu;
             rec[0] = rootc[(Q.root_base ^ c[0]) & 255u];
             uint32_t pool_cnt = 0;
-            double pend_val[1] = {0.0};
-            uint32_t pend_addr[1] = {0u};
-            bool bad = false;
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
-            WalkCtx<1> W{trie, rootc, smem, Q.cold_scores, Q.root_base, 0u, 0u, s, 0u, l32, P.dropout, P.seed};
-            Walk5<DROPOUT, false, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pend_val, pend_addr, pool_cnt, bad);
+            const uint32_t pool_off = 8u * (Q.n_hot + 1u) + slot * (Q.pool_entries * 8u);  // the ring slot's pool
+            WalkCtx<1> W{trie, rootc, smem, Q.cold_scores, Q.root_base, Q.pool_entries, pool_off, s, 0u, l32, P.dropout, P.seed};
+            Walk5<DROPOUT, COLD, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pool_cnt);
+            if (COLD) {
+                __builtin_amdgcn_wave_barrier();
+                if (pool_cnt > Q.pool_entries && lane == 0u) lds_store(&ctrl->bad, 1u);
+                fetch_cold_scores(smem + pool_off, pool_cnt < Q.pool_entries ? pool_cnt : Q.pool_entries, lane, Q.cold_scores);
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0u) lds_store(&ctrl->walk_done[slot], t + 1u);
         }
@@ -627,8 +648,8 @@ hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out) {
 }
 
 // LDS of an encode6_kernel block: score table, root records, control words, ring of `slots` match-index buffers
-uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t slots, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
-    const uint32_t score_bytes = 8u * (n_hot + 1u);
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool_entries, uint32_t slots, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
+    const uint32_t score_bytes = 8u * (n_hot + 1u) + slots * pool_entries * 8u;  // table + one pool per ring slot
     if (score_bytes > 65536u || slots > 24u) return 0;
     const uint32_t ro = (score_bytes + 15u) & ~15u;
     const uint32_t co = ro + 2048u;
@@ -638,11 +659,13 @@ uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t slots, uint32_t* root_off, 
     if (ring_off) *ring_off = go;
     return go + slots * kE5GroupBytes;
 }
-hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, int walkers, uint32_t blocks, hipStream_t stream) {
+hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, int walkers, uint32_t blocks, hipStream_t stream) {
     q.ring_slots = (uint32_t)walkers + 2u;
-    const uint32_t lds = encode6_lds_layout(q.n_hot, q.ring_slots, &q.root_off, &q.ctrl_off, &q.ring_off);
+    if (!cold) q.pool_entries = 0u;
+    const uint32_t lds = encode6_lds_layout(q.n_hot, q.pool_entries, q.ring_slots, &q.root_off, &q.ctrl_off, &q.ring_off);
     if (lds == 0 || lds > 160u * 1024u || walkers < 1 || walkers > 15) return hipErrorInvalidValue;
-    auto fn = p.dropout > 0.0 ? encode6_kernel<true> : encode6_kernel<false>;
+    auto fn = cold ? (p.dropout > 0.0 ? encode6_kernel<true, true> : encode6_kernel<false, true>)
+                   : (p.dropout > 0.0 ? encode6_kernel<true, false> : encode6_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)(walkers + 1)), lds, stream, p, q);

@@ -168,8 +168,9 @@ struct KernelTime {
 constexpr int kMaxTimed = 8;
 // encode5_kernel: values in the LDS score table (the table and the per-wave pools of cold values share the
 // 64 KiB a 16-bit match index can address) and pool entries per wave
-constexpr uint32_t kE5MaxHot = 6600;
-constexpr uint32_t kE5PoolEntries = 64;
+constexpr uint32_t kE5MaxHot = 6600;      // score values in the LDS table when all of a vocabulary's values fit
+constexpr uint32_t kE5MaxHotCold = 4095;  // ... when they do not: 32 KiB of table, 32 KiB of 16-bit addresses for the pools
+constexpr uint32_t kE5PoolWanted = 192;   // entries per wave and iteration that the geometry is chosen for
 
 }  // namespace
 
@@ -349,12 +350,16 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     const bool use2 = !use4 && m->lm <= 32 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
     if (debug_on())
         fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u\n",
-                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? (m->have_trie8 && m->hot_coverage >= 0.85 ? "rows5" : "rows4") : (use2 ? "rows2" : "fused"),
+                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? (m->have_trie8 && !m->has_cold ? "rows5" : "rows4") : (use2 ? "rows2" : "fused"),
                 m->flat.table.size(), p.root_base);
-    // encode5_kernel (8-byte records, score values in LDS) when the table is expected to serve most matches;
-    // TGX_PATH=rows4 / rows5 force either kernel (A/B timing, tests of both paths)
+    // encode5_kernel (8-byte records, score values in LDS) for vocabularies whose distinct score values all fit
+    // its table (generate-style vocabularies: scores are logs of integer counts).  A vocabulary with more values
+    // than that (after an M-step every token has its own) stays on encode4_kernel: the pools that would serve
+    // its cold values (a third of the matches at 32 000 entries) cost what the 16-byte records cost, and every
+    // overflow sends a sample to a second pass (profiles/r02: cold_*).  TGX_PATH=rows4 / rows5 force either
+    // kernel (A/B timing, tests of both paths).
     const bool use5 = use4 && m->have_trie8 && !(force && strcmp(force, "rows4") == 0) &&
-                      (m->hot_coverage >= 0.85 || (force && strcmp(force, "rows5") == 0));
+                      (!m->has_cold || (force && strcmp(force, "rows5") == 0));
     if (use5) {
         // Four positions per lane and iteration: the four walks of a lane are staggered (encode5.hip: Walk5), so
         // more of them hide more of each other's gather latency, and four was the fastest on every corpus shape
@@ -382,8 +387,26 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             const int v = atoi(e);
             if (v >= 1 && v <= 8) bpc = v;
         }
+        // Cold-value pool of a wave (vocabularies whose score values do not all fit the table): one entry per cold
+        // match of an iteration (64 lanes x ppl start positions).  A wave that runs out sends its four samples to
+        // the redo pass, and a 64 KiB sample lives through a thousand iterations, so the pool is made as large as
+        // the 16-bit address space of the match indices (table + pools < 64 KiB) and the block's LDS allow.
+        uint32_t pool = 0;
+        if (m->has_cold) {
+            uint32_t want = kE5PoolWanted;  // fewer waves rather than a pool below this
+            if (const char* e = getenv("TGX_E5_POOL")) want = (uint32_t)std::min(2048, std::max(4, atoi(e)));
+            const uint32_t room16 = 65536u - 8u * (m->n_hot + 1u);
+            for (;; waves--) {
+                const uint32_t fixed = tgx::encode5_lds_layout(m->n_hot, 0u, waves, ppl, nullptr, nullptr);  // table, root, indices
+                const uint32_t budget = 160u * 1024u / (uint32_t)bpc;
+                const uint32_t room = fixed && fixed + 1024u < budget ? std::min(room16, budget - fixed - 1024u) : 0u;
+                pool = std::min<uint32_t>(1024u, room / (8u * (uint32_t)waves)) & ~3u;
+                if (pool >= want || waves == 1) break;
+            }
+            if (pool > want && getenv("TGX_E5_POOL")) pool = want;  // experiments: exactly the size asked for
+        }
         while (waves > 1) {
-            const uint32_t lds = tgx::encode5_lds_layout(m->n_hot, m->has_cold ? kE5PoolEntries : 0u, waves, ppl, nullptr, nullptr);
+            const uint32_t lds = tgx::encode5_lds_layout(m->n_hot, pool, waves, ppl, nullptr, nullptr);
             if (lds != 0 && lds * (uint32_t)bpc <= 160u * 1024u) break;
             waves--;
         }
@@ -398,7 +421,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         q.hot = m->d_hot;
         q.root_base = m->root_base8;
         q.n_hot = m->n_hot;
-        q.pool_entries = m->has_cold ? kE5PoolEntries : 0u;  // no pools for a vocabulary whose values all fit the table
+        q.pool_entries = pool;  // no pools for a vocabulary whose values all fit the table
         q.redo_count = m->d_ctrl + 6;
         q.redo_list = c->d_counts;  // free until the trace writes the token counts
         {   // rows claim several consecutive samples of the order per atomic when samples are short: one global
@@ -416,7 +439,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         // profiles/r02: e6_shapes).  The two run one after the other, so the split is chosen among the powers of
         // two as thresholds by the sum of the two estimates; TGX_LONG_THRESHOLD forces one (0: never).
         uint64_t n_long = 0;
-        if (!m->has_cold && c->n_samples) {
+        if (c->n_samples) {
             const auto count_ge = [&](uint64_t thr) {  // h_sorted_len descends: the long samples are a prefix of the order
                 return (uint64_t)(std::partition_point(c->h_sorted_len.begin(), c->h_sorted_len.end(),
                                                        [thr](uint32_t len) { return len >= thr; }) - c->h_sorted_len.begin());
@@ -450,7 +473,12 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             p6.n_samples = n_long;
             const uint32_t blocks6 = (uint32_t)std::min<uint64_t>(n_long, (uint64_t)m->num_cus * 4);
             time_begin(m, "encode6_kernel");
-            HIP_TRY(tgx::launch_encode6(p6, q, 7, blocks6, m->stream));
+            tgx::Encode5Params q6 = q;  // one pool per ring slot (64 positions)
+            if (m->has_cold) {
+                q6.pool_entries = std::min<uint32_t>(256u, (65536u - 8u * (m->n_hot + 1u)) / (8u * 9u)) & ~3u;
+                if (const char* e = getenv("TGX_E5_POOL")) q6.pool_entries = std::min<uint32_t>(q6.pool_entries, (uint32_t)std::max(4, atoi(e)));
+            }
+            HIP_TRY(tgx::launch_encode6(p6, q6, m->has_cold, 7, blocks6, m->stream));
             time_end(m);
             HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode5_kernel
             p.order = c->d_order + n_long;
@@ -493,9 +521,14 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 r4.order = c->d_counts;
                 r4.n_samples = n_redo;
                 HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
-                const uint32_t b4 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_redo + 39) / 40, (uint64_t)m->num_cus * 2));
+                // few samples: their serial chains are the cost (four positions per lane: 9.1 ms per 64 KiB against
+                // 13.5); many: throughput (one position per lane, ten waves per block)
+                const bool few = n_redo <= (uint64_t)m->num_cus * 20;
+                const int ppl4 = few ? 4 : 1, waves4 = few ? 5 : 10;
+                const uint64_t rows4 = 4 * (uint64_t)waves4;
+                const uint32_t b4 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_redo + rows4 - 1) / rows4, (uint64_t)m->num_cus * (few ? 1 : 2)));
                 time_begin(m, "encode4_kernel");
-                HIP_TRY(tgx::launch_encode4(r4, 1, 10, b4, true, m->stream));
+                HIP_TRY(tgx::launch_encode4(r4, ppl4, waves4, b4, !few, m->stream));
                 time_end(m);
             }
         }
@@ -805,7 +838,7 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
             const int v = atoi(e);
             if (v >= 0 && v <= (int)kE5MaxHot) max_hot = (uint32_t)v;
         }
-        tgx::build_trie8(m->flat, vocab_size ? offs : zero_offs, scores, max_hot, &t8);
+        tgx::build_trie8(m->flat, vocab_size ? offs : zero_offs, scores, max_hot, kE5MaxHotCold, &t8);
         const size_t ns = t8.rec.size();
         HIP_TRY_M(hipMalloc(&m->d_trie8, ns * sizeof(tgx::Trie8Rec)));
         HIP_TRY_M(hipMalloc((void**)&m->d_cold_scores, ns * 8));
@@ -908,7 +941,7 @@ uint64_t tgx_flat_trie_search8(const tgx_flat_trie* t, const uint8_t* bytes, con
     tgx_flat_trie* tm = const_cast<tgx_flat_trie*>(t);
     if (!tm->t8 || tm->t8_max_hot != max_hot) {
         tm->t8.reset(new tgx::Trie8());
-        tgx::build_trie8(t->flat, offs ? offs : zero_offs, scores, max_hot, tm->t8.get());
+        tgx::build_trie8(t->flat, offs ? offs : zero_offs, scores, max_hot, max_hot, tm->t8.get());
         tm->t8_max_hot = max_hot;
     }
     const tgx::Trie8& t8 = *tm->t8;

@@ -256,7 +256,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
 }
 
 // ---- 8-byte label-checked records + score table (encode5_kernel) ----------------------------------------
-void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, uint32_t max_hot, Trie8* out) {
+void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, uint32_t max_hot, uint32_t max_hot_cold, Trie8* out) {
     const uint32_t n_slots = (uint32_t)ft.table.size();
     out->rec.assign(n_slots, Trie8Rec{0, 0});
     out->cold_scores.assign(n_slots, 0.0);
@@ -294,7 +294,9 @@ void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores,
         if (vals[a].weight != vals[b].weight) return vals[a].weight > vals[b].weight;
         return vals[a].bits < vals[b].bits;
     });
-    const uint32_t n_hot = (uint32_t)std::min<size_t>(order.size(), max_hot);
+    // all values in the table if they fit; otherwise a smaller table, which leaves the kernels room for the
+    // per-wave pools the cold values go through (table + pools share 64 KiB of 16-bit addresses)
+    const uint32_t n_hot = order.size() <= max_hot ? (uint32_t)order.size() : std::min(max_hot, max_hot_cold);
     std::vector<uint32_t> rank(vals.size(), 0xFFFFFFFFu);
     double hot_w = 0.0;
     out->hot.resize(n_hot);

@@ -68,7 +68,7 @@ struct Trie8 {
     uint32_t root_base = 0;
     double hot_coverage = 1.0;        // expected share of the matches whose score is in the table
 };
-void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, uint32_t max_hot, Trie8* out);
+void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, uint32_t max_hot, uint32_t max_hot_cold, Trie8* out);
 uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const uint8_t* s, uint64_t n, uint32_t* ids,
                                     uint32_t* lens, uint64_t cap);
 
