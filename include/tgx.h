@@ -235,6 +235,12 @@ void tgx_free(void *p);
  * pooled buffer of `device` (all devices if negative) to the HIP runtime, e.g. before another library needs
  * the memory. */
 void tgx_pool_trim(int device);
+/* Page-locked host memory for the buffers a caller hands to tgx_encode_batch_host / tgx_corpus_upload and
+ * receives ids in: copies from and to such memory are DMA transfers at the link's rate, copies from and to
+ * ordinary (pageable) memory go through the driver's staging buffers at about half of it.  NULL (and
+ * tgx_last_error) on failure.  (The reference has no counterpart: its tokenizer runs on the host.) */
+void *tgx_host_alloc(uint64_t bytes);
+void tgx_host_free(void *p);
 
 /* ---- prune host logic (no device needed) ---------------------
  * The O(V) steps of ModelVocabularyPruner between the corpus passes above. */

@@ -478,6 +478,15 @@ def test_host_to_host_entry_point_chunks_and_errors(monkeypatch):
         ids, oo = nat.encode_batch_host(flat, offs)
         np.testing.assert_array_equal(ids, want_ids)
         np.testing.assert_array_equal(oo, want_offs)
+    # caller buffers in page-locked memory (tgx_host_alloc): same result, and the memory is given back
+    from tokengeex_amd import _lib
+    pf, po = _lib.pinned_empty(flat.shape, np.uint8), _lib.pinned_empty(offs.shape, np.uint64)
+    pi = _lib.pinned_empty(int(want_ids.size) + 8, np.uint32)
+    pf[:], po[:] = flat, offs
+    ids, oo = nat.encode_batch_host(pf, po, ids_out=pi)
+    np.testing.assert_array_equal(ids, want_ids)
+    np.testing.assert_array_equal(oo, want_offs)
+    del ids, pf, po, pi
     ids, oo = nat.encode_batch_host(flat, offs, dropout=0.2, seed=5)      # dropout: one chunk, global sample indices
     w2, o2 = ora.encode_batch_flat(flat, offs, 0.2, 5, threads=8)
     np.testing.assert_array_equal(ids, w2)

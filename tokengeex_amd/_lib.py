@@ -74,6 +74,8 @@ SYMBOLS = {
     "tgx_generate_u01": (_d, [_u64, _u64, _u64]),
     "tgx_free": (None, [_vp]),
     "tgx_pool_trim": (None, [_i]),
+    "tgx_host_alloc": (_vp, [_u64]),
+    "tgx_host_free": (None, [_vp]),
     "tgx_digamma": (_d, [_d]),
     "tgx_prune_m_step": (_i, [_vp, _vp, _u32, _vp, _vp, C.POINTER(C.c_uint32)]),
     "tgx_prune_alternatives": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _pvp]),
@@ -123,6 +125,33 @@ def check(status: int) -> None:
         lib.tgx_last_error_detail(C.byref(s), C.byref(p), C.byref(l))
         raise TokenGeeXError(msg, status, s.value, p.value, l.value)
     raise TokenGeeXError(msg, status)
+
+
+class _PinnedBlock:
+    """Owner of one tgx_host_alloc block; numpy views keep it alive through their base chain."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        self.addr = lib.tgx_host_alloc(self.nbytes)
+        if not self.addr:
+            raise TokenGeeXError(lib.tgx_last_error().decode("utf-8", "replace"))
+        self.buf = (C.c_ubyte * max(1, self.nbytes)).from_address(self.addr)
+
+    def __del__(self):
+        addr, self.addr = getattr(self, "addr", None), None
+        if addr:
+            lib.tgx_host_free(addr)
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """numpy array over page-locked host memory (tgx_host_alloc): uploads from it and downloads into it are
+    DMA transfers at the PCIe link's rate."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    blk = _PinnedBlock(n * dt.itemsize)
+    arr = np.frombuffer(blk.buf, dtype=dt, count=n).reshape(shape)
+    blk.buf._tgx_owner = blk  # the array's base is blk.buf: the block lives as long as any view of it
+    return arr
 
 
 def pool_trim(device: int = -1) -> None:

@@ -388,171 +388,235 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
 
 // ---- encode6_kernel: long samples ---------------------------------------------------------------------------
 // A sample is a serial chain: in encode5_kernel a row walks 64 positions, relaxes them, walks the next 64, so a
-// 64 KiB sample takes 1024 x (walk + relax) = 8 ms however idle the chip is, and batches of a few hundred MB
+// 64 KiB sample takes 1024 x (walk + relax) = 6.8 ms however idle the chip is, and batches of a few hundred MB
 // (the per-GPU shards of the prune and merge passes, a 10 MB batch) are bound by their longest samples.  Only
-// the relaxation is serial — the walks of different positions are independent — so this kernel gives every
-// long sample a whole block: seven WALKER waves fill a ring of match-index buffers (64 positions per trip, the
-// walk of encode5_kernel) ahead of one RELAXER wave, which consumes the trips in order, so the sample's chain is
-// 16 relax steps per 16 positions and nothing else.  Hand-over inside the block through LDS words:
-//   epoch        relaxer -> walkers: a new sample's (index, begin, length, first trip) is published
+// the relaxation is serial — the walks of different positions are independent — so this kernel keeps FOUR long
+// samples per block, one per 16-lane row of the RELAXER wave (wave 0), and gives each of them kE6Walkers WALKER
+// waves that fill a ring of match-index buffers (64 positions per trip, the walk of encode5_kernel) ahead of
+// the relaxer, which consumes the trips in order: a sample's chain is 16 relax steps per 16 positions and
+// nothing else.  Hand-over inside the block through LDS words, one set per row (E6Ctrl):
+//   epoch        relaxer -> walkers of the row: a new sample's (index, begin, length, first trip) is published
 //   walk_done[i] walker -> relaxer: ring slot i holds trip (value - 1)
 //   relax_done   relaxer -> walkers: trips consumed so far (slot t % G is free once t < relax_done + G)
-// Trip ids run on across samples, so the words never need resetting.  LDS operations of a wave are performed
-// in order and the LDS is one pipeline per CU, so a flag written after the data is seen after the data.
-// Same back-pointer bytes and status as encode5_kernel (its relaxation, row 0 of the wave), same trace kernel.
+//   ack[j]       walker j -> relaxer: the epoch it has read; the next sample's fields are written only after all
+//                of the row's walkers have read the current ones (a walker without a trip in a short sample
+//                could otherwise still be reading them)
+// Trip ids of a row run on across its samples, so the words never need resetting.  LDS operations of a wave are
+// performed in order and the LDS is one pipeline per CU, so a flag written after the data is seen after the
+// data.  The four rows advance in lockstep (the relaxer waits until every live row's next trip is there): rows
+// have walkers of their own and the same cost per trip, and the order of the samples is longest-first, so
+// rows of a block finish close to each other.  Every wait is on a word that another wave of the same block
+// advances without waiting for the waiter: walkers wait for `epoch` and `relax_done` (the relaxer advances both
+// after waiting only for walk_done words of trips whose slots are free), the relaxer for `walk_done`.
+// Same back-pointer bytes and status as encode5_kernel (its relaxation), same trace kernel.
+constexpr uint32_t kE6Walkers = 3;               // walker waves per sample
+constexpr uint32_t kE6Slots = kE6Walkers + 2u;   // ring slots per sample
 struct E6Ctrl {
-    uint32_t epoch;       // 0 = nothing yet, 0xFFFFFFFF = no more samples
+    uint32_t epoch;       // 0 = nothing yet, 0xFFFFFFFF = no more samples for this row
     uint32_t s, n, trip0;
     uint64_t beg;
     uint32_t relax_done;
     uint32_t bad;         // COLD: a walker of the current sample ran out of pool entries (the sample is redone)
-    uint32_t walk_done[24];
+    uint32_t walk_done[8];
+    uint32_t ack[4];      // walker j -> relaxer: the epoch whose (s, n, beg, trip0) it has read
 };
 constexpr uint32_t kE6Done = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// the four score values of a quarter group (steps 4 q .. 4 q + 3) of a lane: 16-bit LDS addresses in iw
+__device__ __forceinline__ void e6_load_quarter(const unsigned char* smem, const uint32_t (&iw)[8], int q, double (&sv)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int v = 4 * q + u;
+        const uint32_t a = (v & 1) ? (iw[v >> 1] >> 16) : (iw[v >> 1] & 0xFFFFu);
+        sv[u] = *reinterpret_cast<const double*>(smem + a);
+    }
+}
+
 template <bool DROPOUT, bool COLD>
-__global__ __launch_bounds__(512) void encode6_kernel(EncodeParams P, Encode5Params Q) {
+__global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(EncodeParams P, Encode5Params Q) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
+    constexpr uint32_t K = kE6Walkers, G = kE6Slots;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t K = (blockDim.x >> 6) - 1u, G = Q.ring_slots;
     const uint2* __restrict__ trie = reinterpret_cast<const uint2*>(Q.trie8);
     double* const score_tab = reinterpret_cast<double*>(smem);
     const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
-    E6Ctrl* ctrl = reinterpret_cast<E6Ctrl*>(smem + Q.ctrl_off);
+    E6Ctrl* const ctrl_all = reinterpret_cast<E6Ctrl*>(smem + Q.ctrl_off);
     {
         const double ninf_ = -__builtin_huge_val();
         for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = i ? Q.hot[i - 1u] : ninf_;
         uint2* rw = reinterpret_cast<uint2*>(smem + Q.root_off);
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
-        uint32_t* cw = reinterpret_cast<uint32_t*>(ctrl);
-        for (uint32_t i = threadIdx.x; i < sizeof(E6Ctrl) / 4u; i += blockDim.x) cw[i] = 0u;
+        uint32_t* cw = reinterpret_cast<uint32_t*>(ctrl_all);
+        for (uint32_t i = threadIdx.x; i < 4u * sizeof(E6Ctrl) / 4u; i += blockDim.x) cw[i] = 0u;
+        // the ring starts as "no token" everywhere: rows without a sample read it while the others relax
+        uint4* ring = reinterpret_cast<uint4*>(smem + Q.ring_off);
+        for (uint32_t i = threadIdx.x; i < 4u * G * kE5GroupBytes / 16u; i += blockDim.x) ring[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
     const double ninf = -__builtin_huge_val();
 
     if (wave == 0u) {
-        // ================= relaxer =================
-        uint32_t trip0 = 0, epoch = 0;
+        // ================= relaxer: row r of this wave owns one sample at a time =================
+        // (its chain of dependent steps is what a sample waits for: it issues ahead of the walkers on its SIMD)
+        __builtin_amdgcn_s_setprio(3);
+        E6Ctrl* const ctrl = ctrl_all + r;
+        uint32_t s = 0, n = 0, n_trips = 0, tau = 0, trip0 = 0, epoch = 0, slot = 0;
+        uint64_t beg = 0;
+        bool live = false, need_new = true, exhausted = false;
+        double acc = ninf;
+        uint32_t bpv = kNoStep, pk = 0, pk_j = 0;
+        bool pk_dirty = false;
         for (;;) {
-            const uint64_t k = wave_fetch_add(P.queue, 1u);
-            if (k >= P.n_samples) {
-                if (lane == 0u) lds_store(&ctrl->epoch, kE6Done);
-                break;
+            if (__builtin_amdgcn_ballot_w64(need_new) != 0) {
+                for (;;) {  // the row's walkers have read the sample that is being replaced
+                    const bool read = !need_new || epoch == 0u || l >= K || lds_load(&ctrl->ack[l]) == epoch;
+                    if (__builtin_amdgcn_ballot_w64(!read) == 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const uint64_t k = claim_rows(P.queue, need_new && !exhausted, r);
+                if (need_new) {
+                    live = !exhausted && k < P.n_samples;
+                    if (live) {
+                        s = P.order[k];
+                        beg = P.offs[s];
+                        n = (uint32_t)(P.offs[s + 1] - beg);
+                        n_trips = n / 64u + 1u;
+                        tau = 0;
+                        acc = (l == 0u) ? 0.0 : ninf;
+                        bpv = kNoStep;
+                        pk_dirty = false;
+                        if (l == 0u) {
+                            ctrl->s = s;
+                            ctrl->n = n;
+                            ctrl->beg = beg;
+                            ctrl->trip0 = trip0;
+                        }
+                    } else {
+                        exhausted = true;  // the queue only grows: nothing more for this row
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (need_new) {
+                    if (live) epoch++;
+                    if (l == 0u) lds_store(&ctrl->epoch, live ? epoch : kE6Done);
+                }
+                need_new = false;
             }
-            const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
-            const uint64_t beg = first_u64(P.offs[s]);
-            const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
-            const uint32_t n_trips = n / 64u + 1u;
-            if (lane == 0u) {
-                ctrl->s = s;
-                ctrl->n = n;
-                ctrl->beg = beg;
-                ctrl->trip0 = trip0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            epoch++;
-            if (lane == 0u) lds_store(&ctrl->epoch, epoch);
+            if (__builtin_amdgcn_ballot_w64(live) == 0) break;
 
-            double acc = (l == 0u) ? 0.0 : ninf;
-            uint32_t bpv = kNoStep;
-            uint32_t pk = 0, pk_j = 0;
-            bool pk_dirty = false;
-            uint8_t* const bpw = P.bp8 + bp8_base(beg, s);
-            uint32_t slot = trip0 % G;
-            for (uint32_t tau = 0; tau < n_trips; ++tau, slot = (slot + 1u == G) ? 0u : slot + 1u) {
-                const uint32_t t = trip0 + tau;
-                while (lds_load(&ctrl->walk_done[slot]) != t + 1u) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const uint32_t p0 = tau * 64u;
-                const unsigned char* sbase = smem + Q.ring_off + slot * kE5GroupBytes;
-                uint32_t fin[4];
-                bool reached[4];
-                uint32_t pg[4];
+            // ---- every live row's next trip must be in its ring slot
+            const uint32_t t = trip0 + tau;
+            for (;;) {
+                const bool ready = !live || lds_load(&ctrl->walk_done[slot]) == t + 1u;
+                if (__builtin_amdgcn_ballot_w64(!ready) == 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+            const uint32_t p0 = tau * 64u;
+            const unsigned char* sbase = smem + Q.ring_off + (r * G + slot) * kE5GroupBytes + ((l - 1u) & 15u) * 32u;
+            // index words one group ahead, score values half a group ahead of the steps that use them
+            auto load_iw = [&](int g, uint32_t (&iw)[8]) {
+                const uint4* ip = reinterpret_cast<const uint4*>(sbase + g * kE5RowStride);
+                const uint4 ia = ip[0], ib = ip[1];
+                iw[0] = ia.x; iw[1] = ia.y; iw[2] = ia.z; iw[3] = ia.w;
+                iw[4] = ib.x; iw[5] = ib.y; iw[6] = ib.z; iw[7] = ib.w;
+            };
+            const double acc_in = acc;
+            const uint32_t bpv_in = bpv;
+            uint32_t fin[4];
+            bool reached[4];
+            uint32_t iwa[8], iwb[8];
+            double sva[4], svb[4];
+            load_iw(0, iwa);
+            e6_load_quarter(smem, iwa, 0, sva);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t (&iw)[8] = (g & 1) ? iwb : iwa;
+                uint32_t (&iwn)[8] = (g & 1) ? iwa : iwb;
+                fin[g] = kNoStep;
+                uint32_t fhi = 0xFFF00000u;
+                e6_load_quarter(smem, iw, 1, svb);
+                if (g < 3) load_iw(g + 1, iwn);
+                relax5_step<0>(sva[0], acc, bpv, fin[g], fhi);
+                relax5_step<1>(sva[1], acc, bpv, fin[g], fhi);
+                relax5_step<2>(sva[2], acc, bpv, fin[g], fhi);
+                relax5_step<3>(sva[3], acc, bpv, fin[g], fhi);
+                e6_load_quarter(smem, iw, 2, sva);
+                relax5_step<4>(svb[0], acc, bpv, fin[g], fhi);
+                relax5_step<5>(svb[1], acc, bpv, fin[g], fhi);
+                relax5_step<6>(svb[2], acc, bpv, fin[g], fhi);
+                relax5_step<7>(svb[3], acc, bpv, fin[g], fhi);
+                e6_load_quarter(smem, iw, 3, svb);
+                relax5_step<8>(sva[0], acc, bpv, fin[g], fhi);
+                relax5_step<9>(sva[1], acc, bpv, fin[g], fhi);
+                relax5_step<10>(sva[2], acc, bpv, fin[g], fhi);
+                relax5_step<11>(sva[3], acc, bpv, fin[g], fhi);
+                if (g < 3) e6_load_quarter(smem, iwn, 0, sva);
+                relax5_step<12>(svb[0], acc, bpv, fin[g], fhi);
+                relax5_step<13>(svb[1], acc, bpv, fin[g], fhi);
+                relax5_step<14>(svb[2], acc, bpv, fin[g], fhi);
+                relax5_step<15>(svb[3], acc, bpv, fin[g], fhi);
+                reached[g] = fhi != 0xFFF00000u;
+            }
+            if (!live) {  // a row without a sample went through the motions on an all-"no token" slot
+                acc = acc_in;
+                bpv = bpv_in;
+            }
+            // the slot's entries are consumed: its walker-to-be may reset and refill it
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (live && l == 0u) lds_store(&ctrl->relax_done, t + 1u);
+            // back-pointer bytes (encode5_kernel's packed, permuted layout)
+            if (live) {
+                uint8_t* const bpw = P.bp8 + bp8_base(beg, s);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    pg[g] = p0 + 16u * g + l;
-                    fin[g] = kNoStep;
-                    // every row of the wave relaxes the same 16 positions (group g of the trip): row 0 counts
-                    const uint4* ip = reinterpret_cast<const uint4*>(sbase + g * kE5RowStride + ((l - 1u) & 15u) * 32u);
-                    const uint4 ia = ip[0], ib = ip[1];
-                    const uint32_t iw[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-                    uint32_t fhi = 0xFFF00000u;
-                    double sv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
-                        sv[u] = *reinterpret_cast<const double*>(smem + a);
-                    }
-                    relax5_step<0>(sv[0], acc, bpv, fin[g], fhi);
-                    relax5_step<1>(sv[1], acc, bpv, fin[g], fhi);
-                    relax5_step<2>(sv[2], acc, bpv, fin[g], fhi);
-                    relax5_step<3>(sv[3], acc, bpv, fin[g], fhi);
-                    relax5_step<4>(sv[4], acc, bpv, fin[g], fhi);
-                    relax5_step<5>(sv[5], acc, bpv, fin[g], fhi);
-                    relax5_step<6>(sv[6], acc, bpv, fin[g], fhi);
-                    relax5_step<7>(sv[7], acc, bpv, fin[g], fhi);
-#pragma unroll
-                    for (int u = 8; u < 16; ++u) {
-                        const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
-                        sv[u - 8] = *reinterpret_cast<const double*>(smem + a);
-                    }
-                    relax5_step<8>(sv[0], acc, bpv, fin[g], fhi);
-                    relax5_step<9>(sv[1], acc, bpv, fin[g], fhi);
-                    relax5_step<10>(sv[2], acc, bpv, fin[g], fhi);
-                    relax5_step<11>(sv[3], acc, bpv, fin[g], fhi);
-                    relax5_step<12>(sv[4], acc, bpv, fin[g], fhi);
-                    relax5_step<13>(sv[5], acc, bpv, fin[g], fhi);
-                    relax5_step<14>(sv[6], acc, bpv, fin[g], fhi);
-                    relax5_step<15>(sv[7], acc, bpv, fin[g], fhi);
-                    reached[g] = fhi != 0xFFF00000u;
-                }
-                // the slot's entries are consumed: its walker-to-be may reset and refill it
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0u) lds_store(&ctrl->relax_done, t + 1u);
-                // back-pointer bytes (encode5_kernel's packed, permuted layout); row 0 stores
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (pg[g] >= 1u && pg[g] <= n) {
+                    const uint32_t pgq = p0 + 16u * g + l;
+                    if (pgq >= 1u && pgq <= n) {
                         const uint32_t b = reached[g] ? ((l - fin[g] - 1u) & 15u) : 0xFFu;
-                        const uint32_t j = pg[g] - 1u, kq = (j >> 4) & 3u;
+                        const uint32_t j = pgq - 1u, kq = (j >> 4) & 3u;
                         pk = (kq == 0u) ? b : (pk | (b << (8u * kq)));
                         pk_j = j;
                         pk_dirty = true;
                         if (kq == 3u) {
-                            if (r == 0u) __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(j) & ~3u)));
+                            __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(j) & ~3u)));
                             pk_dirty = false;
                         }
                     }
+                }
                 const uint32_t left = n - p0;
-                if (left < 64u) {
-                    if (pk_dirty && r == 0u) __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(pk_j) & ~3u)));
+                if (left < 64u) {  // the sample's last trip
+                    if (pk_dirty) __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(pk_j) & ~3u)));
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        if (r == 0u && left == 16u * g + l) P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
-                }
-            }
-            if (COLD) {  // every walker of this sample has published its last trip (acquired above)
-                if (lds_load(&ctrl->bad) != 0u) {
-                    if (lane == 0u) {
-                        const unsigned long long at = atomicAdd(Q.redo_count, 1ull);
-                        Q.redo_list[at] = s;
-                        lds_store(&ctrl->bad, 0u);
+                        if (left == 16u * g + l) P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
+                    if (COLD) {  // every walker of this sample has published its last trip (acquired above)
+                        if (l == 0u && lds_load(&ctrl->bad) != 0u) {
+                            const unsigned long long at = atomicAdd(Q.redo_count, 1ull);
+                            Q.redo_list[at] = s;
+                            lds_store(&ctrl->bad, 0u);
+                        }
                     }
+                    trip0 += n_trips;
+                    need_new = true;
+                } else {
+                    tau++;
                 }
+                slot = (slot + 1u == G) ? 0u : slot + 1u;
             }
-            trip0 += n_trips;
         }
         return;
     }
 
-    // ================= walkers =================
-    const uint32_t w = wave - 1u;
+    // ================= walkers: wave w serves row (w - 1) & 3 as its walker number (w - 1) >> 2 =================
+    const uint32_t rw = (wave - 1u) & 3u, jw = (wave - 1u) >> 2;
+    E6Ctrl* const ctrl = ctrl_all + rw;
     uint32_t seen = 0;
     for (;;) {
         uint32_t e;
@@ -562,8 +626,10 @@ __global__ __launch_bounds__(512) void encode6_kernel(EncodeParams P, Encode5Par
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const uint32_t s = ctrl->s, n = ctrl->n, trip0 = ctrl->trip0;
         const uint64_t beg = ctrl->beg;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the reads above stay above the acknowledgement
+        if (lane == 0u) lds_store(&ctrl->ack[jw], e);
         const uint32_t n_trips = n / 64u + 1u;
-        const uint32_t tau0 = (w + K - trip0 % K) % K;
+        const uint32_t tau0 = (jw + K - trip0 % K) % K;
         uint32_t slot = (trip0 + tau0) % G;
         for (uint32_t tau = tau0; tau < n_trips; tau += K, slot = (slot + K >= G) ? slot + K - G : slot + K) {
             const uint32_t t = trip0 + tau;
@@ -581,7 +647,7 @@ __global__ __launch_bounds__(512) void encode6_kernel(EncodeParams P, Encode5Par
 #pragma unroll
             for (int q = 0; q < 4; ++q) bytes[0][q] = __builtin_amdgcn_alignbyte(wv[q + 1], wv[q], sh);
             // reset this lane's reader column of its group, then walk
-            const uint32_t slot_off = Q.ring_off + slot * kE5GroupBytes;
+            const uint32_t slot_off = Q.ring_off + (rw * G + slot) * kE5GroupBytes;
             {
                 uint4* mine = reinterpret_cast<uint4*>(smem + slot_off + r * kE5RowStride + ((l - 1u) & 15u) * 32u);
                 mine[0] = make_uint4(0, 0, 0, 0);
@@ -600,7 +666,7 @@ __global__ __launch_bounds__(512) void encode6_kernel(EncodeParams P, Encode5Par
             uint32_t pool_cnt = 0;
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
-            const uint32_t pool_off = 8u * (Q.n_hot + 1u) + slot * (Q.pool_entries * 8u);  // the ring slot's pool
+            const uint32_t pool_off = 8u * (Q.n_hot + 1u) + (rw * G + slot) * (Q.pool_entries * 8u);  // the ring slot's pool
             WalkCtx<1> W{trie, rootc, smem, Q.cold_scores, Q.root_base, Q.pool_entries, pool_off, s, 0u, l32, P.dropout, P.seed};
             Walk5<DROPOUT, COLD, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pool_cnt);
             if (COLD) {
@@ -647,28 +713,33 @@ hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out) {
     return hipSuccess;
 }
 
-// LDS of an encode6_kernel block: score table, root records, control words, ring of `slots` match-index buffers
-uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool_entries, uint32_t slots, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
-    const uint32_t score_bytes = 8u * (n_hot + 1u) + slots * pool_entries * 8u;  // table + one pool per ring slot
-    if (score_bytes > 65536u || slots > 24u) return 0;
+// LDS of an encode6_kernel block: score table, one pool per ring slot (COLD), root records, control words of
+// the four rows, four rings of kE6Slots match-index buffers
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool_entries, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
+    const uint32_t score_bytes = 8u * (n_hot + 1u) + 4u * kE6Slots * pool_entries * 8u;
+    if (score_bytes > 65536u) return 0;
     const uint32_t ro = (score_bytes + 15u) & ~15u;
     const uint32_t co = ro + 2048u;
-    const uint32_t go = (co + (uint32_t)sizeof(E6Ctrl) + 511u) & ~511u;
+    const uint32_t go = (co + 4u * (uint32_t)sizeof(E6Ctrl) + 511u) & ~511u;
     if (root_off) *root_off = ro;
     if (ctrl_off) *ctrl_off = co;
     if (ring_off) *ring_off = go;
-    return go + slots * kE5GroupBytes;
+    return go + 4u * kE6Slots * kE5GroupBytes;
 }
-hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, int walkers, uint32_t blocks, hipStream_t stream) {
-    q.ring_slots = (uint32_t)walkers + 2u;
+uint32_t encode6_max_pool_entries(uint32_t n_hot) {
+    const uint32_t room = 65536u - 8u * (n_hot + 1u);
+    return std::min<uint32_t>(256u, room / (8u * 4u * kE6Slots)) & ~3u;
+}
+hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream) {
+    q.ring_slots = kE6Slots;
     if (!cold) q.pool_entries = 0u;
-    const uint32_t lds = encode6_lds_layout(q.n_hot, q.pool_entries, q.ring_slots, &q.root_off, &q.ctrl_off, &q.ring_off);
-    if (lds == 0 || lds > 160u * 1024u || walkers < 1 || walkers > 15) return hipErrorInvalidValue;
+    const uint32_t lds = encode6_lds_layout(q.n_hot, q.pool_entries, &q.root_off, &q.ctrl_off, &q.ring_off);
+    if (lds == 0 || lds > 160u * 1024u) return hipErrorInvalidValue;
     auto fn = cold ? (p.dropout > 0.0 ? encode6_kernel<true, true> : encode6_kernel<false, true>)
                    : (p.dropout > 0.0 ? encode6_kernel<true, false> : encode6_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)(walkers + 1)), lds, stream, p, q);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (1u + 4u * kE6Walkers)), lds, stream, p, q);
     return hipGetLastError();
 }
 

@@ -148,8 +148,9 @@ uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
 uint32_t encode5_lds_layout(uint32_t n_hot, uint32_t pool_entries, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off);
 hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out);
-uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool_entries, uint32_t slots, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
-hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, int walkers, uint32_t blocks, hipStream_t stream);
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool_entries, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
+uint32_t encode6_max_pool_entries(uint32_t n_hot);
+hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip
 hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream);

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -432,11 +433,11 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         m->last_redo_samples = 0;
         if (m->has_cold) HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
-        // Long samples first, each with a block of its own (encode6_kernel: seven walker waves ahead of one
-        // relaxing wave), when that shortens the pass.  encode5_kernel takes ~0.104 us per byte of a sample's
-        // serial chain (6.8 ms per 64 KiB) and ~1 s per 88 GB of batch; encode6_kernel ~0.034 us per byte of
-        // chain (2.25 ms per 64 KiB) but only ~25 GB/s once every CU has its blocks (one relaxing wave per block;
-        // profiles/r02: e6_shapes).  The two run one after the other, so the split is chosen among the powers of
+        // Long samples first, four to a block (encode6_kernel: three walker waves per sample ahead of one row of the
+        // block's relaxing wave), when that shortens the pass.  encode5_kernel takes ~0.104 us per byte of a
+        // sample's serial chain (6.8 ms per 64 KiB) and ~1 s per 88 GB of batch; encode6_kernel ~0.037 us per byte
+        // of chain (2.4 ms per 64 KiB) but ~55 GB/s once every CU has its two blocks (eight relaxing rows per CU;
+        // profiles/r02: e6 shapes).  The two run one after the other, so the split is chosen among the powers of
         // two as thresholds by the sum of the two estimates; TGX_LONG_THRESHOLD forces one (0: never).
         uint64_t n_long = 0;
         if (c->n_samples) {
@@ -451,7 +452,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 const double N = (double)c->n_bytes;
                 auto cost = [&](uint64_t k) {  // the k longest samples to encode6_kernel
                     const double bytes_long = k ? (double)c->h_sorted_cum[k - 1] : 0.0;
-                    const double t6 = k ? std::max((double)c->h_sorted_len[0] * 0.0343e-6, bytes_long / 25e9) + 20e-6 : 0.0;
+                    const double t6 = k ? std::max((double)c->h_sorted_len[0] * 0.0369e-6, bytes_long / 55e9) + 20e-6 : 0.0;
                     const double rest_max = k < c->n_samples ? (double)c->h_sorted_len[k] : 0.0;
                     const double t5 = std::max(rest_max * 0.104e-6, (N - bytes_long) / 88e9);
                     return t6 + t5;
@@ -471,14 +472,17 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         if (n_long) {
             tgx::EncodeParams p6 = p;
             p6.n_samples = n_long;
-            const uint32_t blocks6 = (uint32_t)std::min<uint64_t>(n_long, (uint64_t)m->num_cus * 4);
+            // four samples per block (one per row of its relaxing wave); 13 waves of 69 registers, 60 KiB of LDS: two blocks per CU
+            int e6_bpc = 2;
+            if (const char* e = getenv("TGX_E6_BPC")) e6_bpc = std::min(4, std::max(1, atoi(e)));
+            const uint32_t blocks6 = (uint32_t)std::min<uint64_t>((n_long + 3) / 4, (uint64_t)m->num_cus * (uint64_t)e6_bpc);
             time_begin(m, "encode6_kernel");
             tgx::Encode5Params q6 = q;  // one pool per ring slot (64 positions)
             if (m->has_cold) {
-                q6.pool_entries = std::min<uint32_t>(256u, (65536u - 8u * (m->n_hot + 1u)) / (8u * 9u)) & ~3u;
+                q6.pool_entries = tgx::encode6_max_pool_entries(m->n_hot);
                 if (const char* e = getenv("TGX_E5_POOL")) q6.pool_entries = std::min<uint32_t>(q6.pool_entries, (uint32_t)std::max(4, atoi(e)));
             }
-            HIP_TRY(tgx::launch_encode6(p6, q6, m->has_cold, 7, blocks6, m->stream));
+            HIP_TRY(tgx::launch_encode6(p6, q6, m->has_cold, blocks6, m->stream));
             time_end(m);
             HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode5_kernel
             p.order = c->d_order + n_long;
@@ -741,6 +745,22 @@ int tgx_abi_version(void) { return TGX_ABI_VERSION; }
 int tgx_device_count(void) { return usable_device_count(); }
 void tgx_free(void* p) { free(p); }
 void tgx_pool_trim(int device) { pool_trim(device); }
+void* tgx_host_alloc(uint64_t bytes) {
+    if (usable_device_count() <= 0) {
+        fail(TGX_ERR_DEVICE, "no usable HIP device (gfx950 required)");
+        return nullptr;
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? (size_t)bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        fail(TGX_ERR_DEVICE, "out of page-locked host memory (%llu bytes)", (unsigned long long)bytes);
+        return nullptr;
+    }
+    return p;
+}
+void tgx_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
 
 tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                             uint32_t vocab_size, int device, tgx_model** out) {
@@ -1008,6 +1028,31 @@ double tgx_dropout_u01_host(uint64_t seed, uint64_t sample, uint64_t pos, uint32
 
 // ---- corpus ------------------------------------------------------------------
 
+// Host <-> device copies of corpora and results go through two streams of their own per device (one per
+// direction): synchronous hipMemcpy calls all share the null stream, so an upload from one thread and a download
+// from another took turns on it instead of using the link in both directions (profiles/r02: e2e timeline).
+static hipStream_t copy_stream(int device, int dir) {
+    static std::mutex mu;
+    static hipStream_t streams[64][2] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!streams[device][dir]) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;  // the null stream: correct, only slower
+        }
+        streams[device][dir] = st;
+    }
+    return streams[device][dir];
+}
+static hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, int device) {
+    hipStream_t st = copy_stream(device, kind == hipMemcpyHostToDevice ? 0 : 1);
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);
+}
+
 tgx_status tgx_corpus_upload(int device, const uint8_t* text, const uint64_t* offs,
                              uint64_t n_samples, tgx_corpus** out) {
     if (!out) return fail(TGX_ERR_INVALID, "tgx_corpus_upload: out is NULL");
@@ -1068,7 +1113,7 @@ tgx_status tgx_corpus_upload(int device, const uint8_t* text, const uint64_t* of
     HIP_TRY_C(hipMemset(c->d_text_alloc, 0, 256));
     HIP_TRY_C(pool_alloc(device, (size_t)(n_samples + 1) * 8, (void**)&c->d_offs));
     HIP_TRY_C(pool_alloc(device, (size_t)n_samples * 4 + 4, (void**)&c->d_order));
-    if (c->n_bytes) HIP_TRY_C(hipMemcpy(c->d_text, text + base, c->n_bytes, hipMemcpyHostToDevice));
+    if (c->n_bytes) HIP_TRY_C(copy_sync(c->d_text, text + base, c->n_bytes, hipMemcpyHostToDevice, device));
     HIP_TRY_C(hipMemset(c->d_text + c->n_bytes, 0, 256));
     HIP_TRY_C(hipMemcpy(c->d_offs, c->h_offs.data(), (n_samples + 1) * 8, hipMemcpyHostToDevice));
     if (n_samples) HIP_TRY_C(hipMemcpy(c->d_order, order.data(), n_samples * 4, hipMemcpyHostToDevice));
@@ -1180,8 +1225,8 @@ tgx_status tgx_encode_batch(tgx_model* m, const uint8_t* text, const uint64_t* o
 
 // Host buffers in, host buffers out (what a Rust caller of Tokenizer::encode_batch has: bindings/python/src/lib.rs:51-59
 // hands over borrowed strings and takes owned vectors back).  A large batch is cut at sample boundaries into chunks
-// of 256 MiB that three host threads take through upload -> kernels -> download: the kernels of one chunk run
-// (under the model's lock) while the text of the next goes to the device and the ids of the previous come back, so
+// of 256 MiB that go through three stages — upload, kernels, download — each on a thread of its own: the kernels of
+// one chunk run while the text of the next goes to the device and the ids of the previous come back, so
 // the PCIe link works in both directions beside the kernels instead of before and after them.  ids_out must hold
 // ids_cap entries (at most one token per byte: ids_cap = bytes always suffices); offs_out[n_samples + 1].
 // Dropout passes keep the one-chunk path (the keep rule hashes the sample's index in the batch).
@@ -1212,92 +1257,135 @@ tgx_status tgx_encode_batch_host(tgx_model* m, const uint8_t* text, const uint64
         cut.push_back(n_samples);
     }
     const size_t C = cut.size() - 1;
+    // Three stages, each chunk through them in order: this thread downloads, one thread uploads, one runs the
+    // kernels.  (Workers that each took a chunk through all three stages started their uploads together, shared
+    // the link, and the first kernel waited for all of them.)
     struct ChunkState {
+        tgx_corpus* corpus = nullptr;
+        tgx_result* result = nullptr;
         uint64_t tokens = 0;
-        bool counted = false;
+        int stage = 0;  // 1 uploaded, 2 encoded, 3 downloaded
     };
     std::vector<ChunkState> cs(C);
     std::mutex mu;
     std::condition_variable cv;
-    size_t next_chunk = 0;
     tgx_status first_err = TGX_OK;
-    size_t first_err_chunk = ~size_t(0);
     std::string err_msg;
     uint64_t err_sample = 0, err_pos = 0, err_len = 0;
     bool abort_all = false;
-    auto worker = [&]() {
-        for (;;) {
-            size_t k;
+    size_t downloaded = 0;
+    auto set_error = [&](tgx_status st, uint64_t sample_base) {  // under mu; g_err_* are this thread's
+        if (first_err == TGX_OK) {
+            first_err = st;
+            err_msg = g_err_msg;
+            err_sample = g_err_sample + sample_base;
+            err_pos = g_err_pos;
+            err_len = g_err_len;
+        }
+        abort_all = true;
+        cv.notify_all();
+    };
+    const auto t_start = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what, size_t k, std::chrono::steady_clock::time_point t0) {  // TGX_DEBUG=1: stage timeline
+        if (!debug_on()) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[tgx] e2e chunk %zu %-8s %7.2f -> %7.2f ms\n", k, what,
+                std::chrono::duration<double, std::milli>(t0 - t_start).count(),
+                std::chrono::duration<double, std::milli>(now - t_start).count());
+    };
+    std::thread uploader([&]() {
+        for (size_t k = 0; k < C; k++) {
             {
-                std::lock_guard<std::mutex> lk(mu);
-                if (abort_all || next_chunk >= C) return;
-                k = next_chunk++;
+                std::unique_lock<std::mutex> lk(mu);  // at most three chunks between upload and download
+                cv.wait(lk, [&]() { return abort_all || k < downloaded + 3; });
+                if (abort_all) return;
             }
-            const uint64_t lo = cut[k], hi = cut[k + 1];
-            tgx_result* r = nullptr;
-            tgx_status st = tgx_encode_batch(m, text, offs + lo, hi - lo, dropout, seed, &r);
-            uint64_t base = 0;
+            tgx_corpus* c = nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            const tgx_status st = tgx_corpus_upload(m->device, text, offs + cut[k], cut[k + 1] - cut[k], &c);
+            stamp("upload", k, t0);
+            std::lock_guard<std::mutex> lk(mu);
+            if (st != TGX_OK) {
+                set_error(st, cut[k]);
+                return;
+            }
+            cs[k].corpus = c;
+            cs[k].stage = 1;
+            cv.notify_all();
+        }
+    });
+    std::thread encoder([&]() {
+        for (size_t k = 0; k < C; k++) {
+            tgx_corpus* c = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                if (st != TGX_OK) {
-                    if (k < first_err_chunk) {  // the lowest failing sample of the batch is in the lowest failing chunk
-                        first_err = st;
-                        first_err_chunk = k;
-                        err_msg = g_err_msg;
-                        err_sample = g_err_sample + lo;
-                        err_pos = g_err_pos;
-                        err_len = g_err_len;
-                    }
-                    abort_all = true;
-                    cs[k].counted = true;
-                    cv.notify_all();
-                    continue;
-                }
-                cs[k].tokens = r->n_tokens;
-                cs[k].counted = true;
-                cv.notify_all();
-                cv.wait(lk, [&]() {
-                    if (abort_all) return true;
-                    for (size_t j = 0; j < k; j++)
-                        if (!cs[j].counted) return false;
-                    return true;
-                });
-                if (abort_all) {
-                    lk.unlock();
-                    tgx_result_free(r);
-                    continue;
-                }
-                for (size_t j = 0; j < k; j++) base += cs[j].tokens;
+                cv.wait(lk, [&]() { return abort_all || cs[k].stage >= 1; });
+                if (cs[k].stage < 1) return;  // aborted before this chunk was uploaded
+                c = cs[k].corpus;
+                if (abort_all) continue;      // (the main thread frees what is left)
             }
-            tgx_status st2 = TGX_OK;
-            if (base + r->n_tokens > ids_cap) {
-                st2 = fail(TGX_ERR_INVALID, "tgx_encode_batch_host: ids_out holds %llu ids, the batch has more", (unsigned long long)ids_cap);
-            } else {
-                if (r->n_tokens) st2 = tgx_result_copy_ids(r, ids_out + base, r->n_tokens);
-                if (st2 == TGX_OK) {
-                    std::vector<uint64_t> lo_offs(hi - lo + 1);
-                    st2 = tgx_result_copy_offsets(r, lo_offs.data(), hi - lo + 1);
-                    for (uint64_t i = 0; i <= hi - lo && st2 == TGX_OK; i++) offs_out[lo + i] = base + lo_offs[i];
-                }
+            tgx_result* r = nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            const tgx_status st = tgx_encode_corpus(m, c, dropout, seed, &r);
+            tgx_corpus_free(c);  // text and scratch go back to the pool for the next chunk's upload
+            stamp("kernels", k, t0);
+            std::lock_guard<std::mutex> lk(mu);
+            cs[k].corpus = nullptr;
+            if (st != TGX_OK) {
+                set_error(st, cut[k]);  // chunks are encoded in order: the lowest failing sample of the batch
+                return;
             }
-            tgx_result_free(r);
-            if (st2 != TGX_OK) {
-                std::lock_guard<std::mutex> lk(mu);
-                if (first_err == TGX_OK) {
-                    first_err = st2;
-                    first_err_chunk = k;
-                    err_msg = g_err_msg;
-                }
-                abort_all = true;
-                cv.notify_all();
+            cs[k].result = r;
+            cs[k].tokens = r->n_tokens;
+            cs[k].stage = 2;
+            cv.notify_all();
+        }
+    });
+    uint64_t base = 0;
+    for (size_t k = 0; k < C; k++) {
+        tgx_result* r = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { return abort_all || cs[k].stage >= 2; });
+            if (cs[k].stage < 2) break;
+            r = cs[k].result;
+        }
+        const uint64_t lo = cut[k], hi = cut[k + 1];
+        const auto t0 = std::chrono::steady_clock::now();
+        tgx_status st2 = TGX_OK;
+        if (base + r->n_tokens > ids_cap) {
+            st2 = fail(TGX_ERR_INVALID, "tgx_encode_batch_host: ids_out holds %llu ids, the batch has more", (unsigned long long)ids_cap);
+        } else {
+            if (r->n_tokens) st2 = tgx_result_copy_ids(r, ids_out + base, r->n_tokens);
+            if (st2 == TGX_OK) {
+                std::vector<uint64_t> lo_offs(hi - lo + 1);
+                st2 = tgx_result_copy_offsets(r, lo_offs.data(), hi - lo + 1);
+                for (uint64_t i = 0; i <= hi - lo && st2 == TGX_OK; i++) offs_out[lo + i] = base + lo_offs[i];
             }
         }
-    };
-    const size_t T = std::min<size_t>(3, C);
-    std::vector<std::thread> th;
-    for (size_t i = 1; i < T; i++) th.emplace_back(worker);
-    worker();
-    for (auto& x : th) x.join();
+        base += r->n_tokens;
+        stamp("download", k, t0);
+        std::lock_guard<std::mutex> lk(mu);
+        if (st2 != TGX_OK) {
+            g_err_sample = 0;
+            set_error(st2, 0);
+            break;
+        }
+        cs[k].stage = 3;
+        downloaded = k + 1;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (downloaded < C && first_err == TGX_OK) abort_all = true;  // (cannot happen: a stage that stops sets the error)
+        cv.notify_all();
+    }
+    uploader.join();
+    encoder.join();
+    for (size_t k = 0; k < C; k++) {
+        if (cs[k].result) tgx_result_free(cs[k].result);
+        if (cs[k].corpus) tgx_corpus_free(cs[k].corpus);
+    }
     if (first_err != TGX_OK) {
         g_err_msg = err_msg;
         g_err_sample = err_sample;
@@ -1354,7 +1442,7 @@ tgx_status tgx_result_copy_ids(const tgx_result* r, uint32_t* dst, uint64_t cap)
     if (cap < r->n_tokens) return fail(TGX_ERR_INVALID, "tgx_result_copy_ids: %llu ids, room for %llu", (unsigned long long)r->n_tokens, (unsigned long long)cap);
     if (!r->n_tokens) return TGX_OK;
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipMemcpy(dst, r->d_ids, r->n_tokens * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(dst, r->d_ids, r->n_tokens * 4, hipMemcpyDeviceToHost, r->device));
     return TGX_OK;
 }
 
@@ -1362,7 +1450,7 @@ tgx_status tgx_result_copy_offsets(const tgx_result* r, uint64_t* dst, uint64_t 
     if (!r || !dst) return fail(TGX_ERR_INVALID, "tgx_result_copy_offsets: NULL argument");
     if (cap < r->n_samples + 1) return fail(TGX_ERR_INVALID, "tgx_result_copy_offsets: %llu offsets, room for %llu", (unsigned long long)(r->n_samples + 1), (unsigned long long)cap);
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipMemcpy(dst, r->d_offs, (r->n_samples + 1) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(dst, r->d_offs, (r->n_samples + 1) * 8, hipMemcpyDeviceToHost, r->device));
     return TGX_OK;
 }
 
