@@ -1,16 +1,17 @@
 #!/bin/bash
 # The round's records: rocprofv3 stats + PMC traffic of the default bench command, the bench variants, the
 # prune / merge passes at 1 GiB / 32 K and 256 MiB / 500 K, one prune and one merge run, the shape sweeps.
-# usage: tools/final_profile.sh <outdir-under-gpurun_out>
+# usage: tools/final_profile.sh <outdir-under-gpurun_out> [commit-label]
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$1
 mkdir -p $O
 cd $R
-./tools/profile_bench.sh $1/bench_profile > $O/bench_profile.log 2>&1
+./tools/profile_bench.sh $1/bench_profile ${2:-?} > $O/bench_profile.log 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 for ml in 4096 1024 256; do python bench.py --max-sample-len $ml --no-cpu-baseline --no-e2e > $O/bench_max_sample_len_$ml.json 2>/dev/null; done
 python bench.py --vocab 65536 --no-e2e > $O/bench_vocab_65536.json 2>/dev/null
 python bench.py --kind ascii --no-e2e > $O/bench_ascii.json 2>/dev/null
+python bench.py --distinct-scores --no-e2e > $O/bench_distinct_scores.json 2>/dev/null
 python bench.py --size-mb 4096 --no-cpu-baseline --no-e2e --steps 3 --warmup 1 > $O/bench_4GiB.json 2>/dev/null
 python bench.py --max-token-length 24 --no-cpu-baseline --no-e2e > $O/bench_max_token_24.json 2>/dev/null
 python tests/measure/passes_bench.py 1024 32000 16 > $O/passes_1GiB.json 2>/dev/null
@@ -19,7 +20,6 @@ python tests/measure/passes_bench.py 256 500000 8 > $O/passes_256MiB_500k_vocab.
 python tools/prune_bench.py 256 500000 375000 > $O/prune_256MiB_500k_vocab.json 2> $O/prune_500k.err
 python tools/prune_bench.py 256 32000 16000 > $O/prune_256MiB.json 2>/dev/null
 python tools/merge_bench.py 256 32000 300 100 16 > $O/merge_256MiB.json 2>/dev/null
-python tools/e5_shapes.py > $O/e5_shapes.txt 2>&1
 python tools/e6_shapes.py > $O/e6_shapes.txt 2>&1
 python tests/measure/cpu_port_threads.py > $O/config0_cpu_port_threads.json 2>/dev/null
 ls -la $O
