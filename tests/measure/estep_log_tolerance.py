@@ -1,8 +1,8 @@
 """Deviation of the E-step kernels from the CPU oracle by snippet length, log-domain (TGX_ESTEP=log: the literal
 restatement of src/lattice.rs:245-333) and linear-domain (default) — the figures behind the tolerances in
-BASELINE.md section 3.  Uses oracle/: a measurement script, not product code."""
+BASELINE.md section 3.  Uses oracle/ as the checker: lives under tests/."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import tokengeex_amd as tgx
 from oracle import oracle as orc

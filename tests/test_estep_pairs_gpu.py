@@ -161,6 +161,25 @@ def test_estep_all_kernel_paths_agree(monkeypatch):
     np.testing.assert_allclose(a, b, rtol=rtol_for(20000), atol=ATOL)
 
 
+def test_log_domain_kernels_hold_the_tightest_tolerance_they_meet(monkeypatch):
+    """The literal log-domain restatement (estep4.hip, TGX_ESTEP=log) against the CPU oracle at the tolerances of
+    BASELINE.md section 3: SURVEY's 1e-9 up to 16 KiB snippets (measured 2.8e-10), 6e-9 at 64 KiB (measured 3.4e-9;
+    tests/measure/estep_log_tolerance.py, profiles/r02/v_estep_tolerance_by_snippet.txt)."""
+    flat, offs = synth.make_corpus(4 << 20, "mixed", seed_offset=5)
+    toks, scores = synth.build_vocab(flat[: 2 << 20], 8000, 16)
+    monkeypatch.setenv("TGX_ESTEP", "log")
+    nat, ora = _pair(toks, scores)
+    corpus = tgx.NativeCorpus(flat, offs)
+    for snip, rtol in ((4096, 1e-9), (16384, 1e-9), (65536, 6e-9)):
+        got, gz = nat.estep(corpus, snip)
+        assert "estep4_fwd_kernel" in nat.last_kernel_times()
+        st, want, wz, _ = ora.estep_flat(flat, offs, snip, threads=8)
+        assert st == orc.OK
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=ATOL)
+        assert np.array_equal(got != 0, want != 0)
+        assert abs(gz - wz) <= 1e-12 * abs(wz)
+
+
 def test_estep_falls_back_to_log_domain_when_a_position_has_no_incoming_token():
     """A text byte that is no token leaves a position without an incoming token (lattice.rs:255: it then
     counts as log-probability 0.0), which the linear-domain kernels cannot express: their forward kernel

@@ -12,10 +12,12 @@ def one(vocab: str, size_mb: int):
     import numpy as np
     import tokengeex_amd as tgx
     from tokengeex_amd import synth
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    if vocab == "500k":
-        from util import load_vocab_500k
-        toks, scores = load_vocab_500k()
+    if vocab == "500k":  # the committed 500 000-entry vocabulary of configs[3] (tests/golden/vocab_500000.npz)
+        z = np.load(os.path.join(ROOT, "tests", "golden", "vocab_500000.npz"))
+        fb = z["flat"].tobytes()
+        o = np.concatenate([[0], np.cumsum(z["lens"].astype(np.int64))])
+        toks = [fb[o[i]:o[i + 1]] for i in range(o.size - 1)]
+        scores = z["uscores"][z["inv"]].astype(np.float64)
     else:
         vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
         toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
