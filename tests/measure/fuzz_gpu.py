@@ -43,11 +43,18 @@ for case in range(cases):
     flat, offs = tgx.pack(texts)
     dropout = float(rng.choice([0.0, 0.0, 0.1, 0.5, 1.0]))
     sd = int(rng.integers(0, 1 << 62))
-    os.environ.pop("TGX_PPL", None); os.environ.pop("TGX_EPPL", None)
+    for k in ("TGX_PPL", "TGX_EPPL", "TGX_PATH", "TGX_LONG_THRESHOLD", "TGX_E5_MAX_HOT", "TGX_E5_POOL", "TGX_E2E_CHUNK_MB"):
+        os.environ.pop(k, None)
     if rng.random() < 0.6: os.environ["TGX_PPL"] = str(int(rng.choice([1, 2, 4])))
     if rng.random() < 0.6: os.environ["TGX_EPPL"] = str(int(rng.choice([1, 2, 4])))
+    # round 2: kernel choice (encode5 / encode4), long-sample kernel threshold, score table size (cold values
+    # through the pools), pool size (overflow -> redo pass)
+    if rng.random() < 0.5: os.environ["TGX_PATH"] = str(rng.choice(["rows4", "rows5"]))
+    if rng.random() < 0.5: os.environ["TGX_LONG_THRESHOLD"] = str(int(rng.choice([0, 1, 100, 1000, 30000])))
+    if rng.random() < 0.4: os.environ["TGX_E5_MAX_HOT"] = str(int(rng.choice([0, 3, 40, 500])))
+    if rng.random() < 0.3: os.environ["TGX_E5_POOL"] = str(int(rng.choice([4, 16, 64])))
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
-    tag = f"case {case} max_len={max_len} all_bytes={all_bytes} V={len(toks)} S={len(texts)} N={flat.size} dropout={dropout} env={os.environ.get('TGX_PPL')}/{os.environ.get('TGX_EPPL')}"
+    tag = f"case {case} max_len={max_len} all_bytes={all_bytes} V={len(toks)} S={len(texts)} N={flat.size} dropout={dropout} env={os.environ.get('TGX_PPL')}/{os.environ.get('TGX_EPPL')}/{os.environ.get('TGX_PATH')}/{os.environ.get('TGX_LONG_THRESHOLD')}/{os.environ.get('TGX_E5_MAX_HOT')}/{os.environ.get('TGX_E5_POOL')}"
     try:
         want_ids, want_offs = ora.encode_batch_flat(flat, offs, dropout, sd, threads=8)
         want_err = None
@@ -63,6 +70,11 @@ for case in range(cases):
         print("MISMATCH (error)", tag, want_err, got_err); sys.exit(1)
     if want_err is None and not (np.array_equal(got_ids, want_ids) and np.array_equal(got_offs, want_offs)):
         print("MISMATCH (ids)", tag, nat.last_kernel_times()); sys.exit(1)
+    if want_err is None and dropout == 0.0 and case % 4 == 0:  # the host-to-host entry point, in small chunks
+        os.environ["TGX_E2E_CHUNK_MB"] = "1"
+        hi, ho = nat.encode_batch_host(flat, offs)
+        if not (np.array_equal(hi, want_ids) and np.array_equal(ho, want_offs)):
+            print("MISMATCH (host-to-host)", tag); sys.exit(1)
     # E-step on the same batch (every byte must be coverable for z to be normal: skip otherwise)
     if all_bytes and flat.size:
         snip = int(rng.choice([48, 1000, 4096, 81920]))
