@@ -35,6 +35,11 @@ def test_fails_loudly_without_gpu():
     tk = tgx.Tokenizer([(b"a", -1.0, False)])
     with pytest.raises(tgx.TokenGeeXError):
         tk.encode("a", 0.0)
+    with pytest.raises(tgx.TokenGeeXError):  # page-locked host memory is the HIP runtime's too
+        _lib.pinned_empty(16, np.uint8)
+    from tokengeex_amd.generate import VocabularyGenerator
+    with pytest.raises(tgx.TokenGeeXError):  # generate's substring counting has no host fallback either
+        VocabularyGenerator(8, 1.0).feed(["abc abc"])
 
 
 def test_product_never_imports_oracle():

@@ -145,7 +145,15 @@ def test_corpus_resident_passes_and_count_tokens():
     np.testing.assert_array_equal(freq, np.bincount(want_ids, minlength=len(toks)).astype(np.uint64))
     np.testing.assert_array_equal(freq, ora.count_tokens_flat(flat, offs, threads=8))
     times = nat.last_kernel_times()
-    assert times.get("ids_sort+rle", 0) > 0, times
+    assert times.get("ids_histogram_kernel", 0) > 0, times  # the counters of 6 256 ids fit a block's LDS
+    os.environ["TGX_FREQ_SORT"] = "1"                         # larger vocabularies: radix sort + run-length encode
+    try:
+        np.testing.assert_array_equal(nat.count_tokens(corpus), freq)
+        assert nat.last_kernel_times().get("ids_sort+rle", 0) > 0
+    finally:
+        del os.environ["TGX_FREQ_SORT"]
+    f2 = nat.count_tokens(corpus, freq.copy())                # accumulates into the caller's vector
+    np.testing.assert_array_equal(f2, 2 * freq)
     # a second model on the same resident corpus (prune rebuilds the model every sub-iteration)
     toks2, scores2 = toks[:3000], scores[:3000] * 1.01
     keep = [bytes([b]) for b in range(256)]

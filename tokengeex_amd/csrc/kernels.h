@@ -89,6 +89,9 @@ hipError_t pair_count_sort_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t pair_count_sort(void* temp, size_t temp_bytes, const unsigned int* counts_in, unsigned int* counts_out,
                            const unsigned long long* keys_in, unsigned long long* keys_out, uint64_t n,
                            hipStream_t stream);
+constexpr uint32_t kHistMaxVocab = 36864;  // ids whose u32 counters fit one block's LDS (144 KiB)
+hipError_t launch_ids_histogram(const uint32_t* ids, uint64_t n, uint32_t vocab, unsigned long long* out, uint32_t blocks,
+                                hipStream_t stream);
 hipError_t ids_sort_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t ids_sort(void* temp, size_t temp_bytes, const uint32_t* in, uint32_t* out, uint64_t n,
                     unsigned int end_bit, hipStream_t stream);

@@ -1471,8 +1471,8 @@ tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
     if (m->device != c->device) return fail(TGX_ERR_INVALID, "model and corpus on different devices");
     std::lock_guard<std::mutex> lk(m->mu);
     std::lock_guard<std::mutex> lkc(c->mu);
-    // model.encode(sample, 0.0) for every sample (src/prune.rs:218), then a histogram of the ids by
-    // radix sort + run-length encode
+    // model.encode(sample, 0.0) for every sample (src/prune.rs:218), then a histogram of the ids: per-block LDS
+    // histograms when the vocabulary's counters fit a block's LDS, radix sort + run-length encode otherwise
     tgx_result* r = nullptr;
     tgx_status st = encode_corpus_locked(m, c, 0.0, 0, &r);
     if (st != TGX_OK) return st;
@@ -1480,6 +1480,30 @@ tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
     if (T >= 0xFFFFFFFFull) {
         tgx_result_free(r);
         return fail(TGX_ERR_UNSUPPORTED, "frequency pass over more than 2^32-1 tokens per call");
+    }
+    if (T && m->vocab_size <= tgx::kHistMaxVocab && !getenv("TGX_FREQ_SORT")) {
+        // the vocabulary's counters fit a block's LDS: one private histogram per block (pairs.hip)
+        unsigned long long* d_hist = nullptr;
+        const size_t hb = (size_t)m->vocab_size * 8 + 256;
+        auto done = [&](tgx_status s2) {
+            if (s2 != TGX_OK) (void)hipStreamSynchronize(m->stream);
+            pool_free(m->device, d_hist, hb);
+            tgx_result_free(r);
+            return s2;
+        };
+        if (pool_alloc(m->device, hb, (void**)&d_hist) != hipSuccess) return done(fail(TGX_ERR_DEVICE, "out of device memory (frequency pass)"));
+        if (hipMemsetAsync(d_hist, 0, hb, m->stream) != hipSuccess) return done(fail(TGX_ERR_DEVICE, "memset failed"));
+        time_begin(m, "ids_histogram_kernel");
+        if (tgx::launch_ids_histogram(r->d_ids, T, m->vocab_size, d_hist, (uint32_t)m->num_cus, m->stream) != hipSuccess)
+            return done(fail(TGX_ERR_DEVICE, "histogram launch failed"));
+        time_end(m);
+        std::vector<unsigned long long> hh(m->vocab_size);
+        if (hipMemcpyAsync(hh.data(), d_hist, (size_t)m->vocab_size * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess)
+            return done(fail(TGX_ERR_DEVICE, "frequency pass failed: %s", hipGetErrorString(hipGetLastError())));
+        for (uint32_t i = 0; i < m->vocab_size; i++) freq[i] += hh[i];
+        m->last_alg_bytes = c->n_bytes + 8 * (c->n_samples + 1) + 8ull * m->vocab_size;
+        return done(TGX_OK);
     }
     uint32_t *d_sorted = nullptr, *d_unique = nullptr;
     unsigned int *d_cnt = nullptr, *d_runs = nullptr;
