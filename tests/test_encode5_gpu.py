@@ -147,7 +147,7 @@ def test_long_sample_kernel_with_cold_values(monkeypatch, max_hot, pool):
     assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=11)
 
 
-def test_vocabulary_with_distinct_scores_takes_encode4_by_default():
+def test_vocabulary_with_distinct_scores_takes_encode4_by_default(monkeypatch):
     """After an M-step every token has its own score (src/prune.rs:143-151): more values than the LDS table holds.
     Such a model runs encode4_kernel (16-byte records, f64 scores in the match buffer) unless forced."""
     rng = np.random.default_rng(22)
@@ -156,6 +156,17 @@ def test_vocabulary_with_distinct_scores_takes_encode4_by_default():
     assert_same_encoding(nat, ora, flat, offs)
     kt = nat.last_kernel_times()
     assert "encode4_kernel" in kt and "encode5_kernel" not in kt and nat.last_encode_redo_samples() == 0
+    # ... and its long samples go to encode6_kernel (the build with cold-value pools) where the estimate says so:
+    # a 16 MiB batch of samples <= 64 KiB is bound by the serial chains of its longest samples
+    f2, o2 = synth.make_corpus(16 << 20, "mixed", seed_offset=56)
+    assert_same_encoding(nat, ora, f2, o2)
+    kt = nat.last_kernel_times()
+    assert "encode6_kernel" in kt and "encode4_kernel" in kt and 0 < nat.last_encode_long_samples() < o2.size - 1
+    monkeypatch.setenv("TGX_E5_POOL", "8")          # pools this small overflow: those samples come back to encode4
+    monkeypatch.setenv("TGX_LONG_THRESHOLD", "3000")
+    assert_same_encoding(nat, ora, f2, o2)
+    assert nat.last_encode_redo_samples() > 0
+    assert_same_encoding(nat, ora, f2, o2, dropout=0.2, seed=4)
 
 
 def test_long_sample_threshold_default():

@@ -536,22 +536,22 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode4_kernel(Encod
 #pragma unroll
             for (int u = 0; u < 16; ++u) sv[u] = scr[u * 16];
             uint32_t fhi = 0xFFF00000u;
-            relax4_step<0>(sv[0], acc, bpv, fin[g], fhi);
-            relax4_step<1>(sv[1], acc, bpv, fin[g], fhi);
-            relax4_step<2>(sv[2], acc, bpv, fin[g], fhi);
-            relax4_step<3>(sv[3], acc, bpv, fin[g], fhi);
-            relax4_step<4>(sv[4], acc, bpv, fin[g], fhi);
-            relax4_step<5>(sv[5], acc, bpv, fin[g], fhi);
-            relax4_step<6>(sv[6], acc, bpv, fin[g], fhi);
-            relax4_step<7>(sv[7], acc, bpv, fin[g], fhi);
-            relax4_step<8>(sv[8], acc, bpv, fin[g], fhi);
-            relax4_step<9>(sv[9], acc, bpv, fin[g], fhi);
-            relax4_step<10>(sv[10], acc, bpv, fin[g], fhi);
-            relax4_step<11>(sv[11], acc, bpv, fin[g], fhi);
-            relax4_step<12>(sv[12], acc, bpv, fin[g], fhi);
-            relax4_step<13>(sv[13], acc, bpv, fin[g], fhi);
-            relax4_step<14>(sv[14], acc, bpv, fin[g], fhi);
-            relax4_step<15>(sv[15], acc, bpv, fin[g], fhi);
+            relax5_step<0>(sv[0], acc, bpv, fin[g], fhi);
+            relax5_step<1>(sv[1], acc, bpv, fin[g], fhi);
+            relax5_step<2>(sv[2], acc, bpv, fin[g], fhi);
+            relax5_step<3>(sv[3], acc, bpv, fin[g], fhi);
+            relax5_step<4>(sv[4], acc, bpv, fin[g], fhi);
+            relax5_step<5>(sv[5], acc, bpv, fin[g], fhi);
+            relax5_step<6>(sv[6], acc, bpv, fin[g], fhi);
+            relax5_step<7>(sv[7], acc, bpv, fin[g], fhi);
+            relax5_step<8>(sv[8], acc, bpv, fin[g], fhi);
+            relax5_step<9>(sv[9], acc, bpv, fin[g], fhi);
+            relax5_step<10>(sv[10], acc, bpv, fin[g], fhi);
+            relax5_step<11>(sv[11], acc, bpv, fin[g], fhi);
+            relax5_step<12>(sv[12], acc, bpv, fin[g], fhi);
+            relax5_step<13>(sv[13], acc, bpv, fin[g], fhi);
+            relax5_step<14>(sv[14], acc, bpv, fin[g], fhi);
+            relax5_step<15>(sv[15], acc, bpv, fin[g], fhi);
             reached[g] = fhi != 0xFFF00000u;  // high word of -inf
         }
         __builtin_amdgcn_wave_barrier();

@@ -549,20 +549,95 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         // Two blocks of ten waves per CU (20 x 8 KiB of LDS); rows claim samples dynamically, so the
         // geometry only has to fill the CU.
         int ppl = 1, waves = 10, bpc = 2;
-        {
-            // Positions per lane.  A sample is a serial chain of 16 * ppl positions per trip, so the
-            // longest sample bounds the pass from below, while more positions per lane cost LDS and with
-            // it waves per CU.  Measured on 1 x MI355X (tools/ppl_sweep.py): throughput 60 / 50 / 34 GB/s
-            // and 13.5 / 10.7 / 9.1 ms per 64 KiB of chain for ppl = 1 / 2 / 4; take the smallest estimate.
-            const double gbps[3] = {60.0, 50.0, 34.0}, chain_ms[3] = {13.5, 10.7, 9.1};
+        // Positions per lane.  A sample is a serial chain of 16 * ppl positions per trip, so the longest
+        // sample bounds the pass from below, while more positions per lane cost LDS and with it waves per CU.
+        // Measured on 1 x MI355X (tools/ppl_sweep.py): throughput 60 / 50 / 34 GB/s and 13.5 / 10.7 / 9.1 ms per
+        // 64 KiB of chain for ppl = 1 / 2 / 4; take the smallest estimate.
+        const double gbps4[3] = {60.0, 50.0, 34.0}, chain4_ms[3] = {13.5, 10.7, 9.1};
+        auto cost4 = [&](double bytes, double longest, int* ppl_out) {
             double best_t = 0;
+            int best_ppl = 1;
             for (int i = 0; i < 3; i++) {
-                const double t = std::max((double)c->n_bytes / (gbps[i] * 1e6), (double)c->max_len / 65536.0 * chain_ms[i]);
+                const double t = std::max(bytes / (gbps4[i] * 1e9), longest / 65536.0 * chain4_ms[i] * 1e-3);
                 if (i == 0 || t < best_t * 0.95) {  // switch only for a clear gain
                     best_t = t;
-                    ppl = 1 << i;
+                    best_ppl = 1 << i;
                 }
             }
+            if (ppl_out) *ppl_out = best_ppl;
+            return best_t;
+        };
+        // The longest samples to encode6_kernel (its build with cold-value pools: this branch is where models with
+        // more score values than the LDS table holds end up) when the estimate says the pass gets shorter — the
+        // same choice among powers of two as above, against encode4_kernel's constants.  A sample whose ring slot
+        // ran out of pool entries comes back on the redo list and is encoded below with the rest.
+        uint64_t n_long4 = 0;
+        if (m->have_trie8 && c->n_samples && !(force && strcmp(force, "rows4") == 0 && !getenv("TGX_LONG_THRESHOLD")) &&
+            tgx::encode6_max_pool_entries(m->n_hot) >= 32u) {
+            const auto count_ge = [&](uint64_t thr) {
+                return (uint64_t)(std::partition_point(c->h_sorted_len.begin(), c->h_sorted_len.end(),
+                                                       [thr](uint32_t len) { return len >= thr; }) - c->h_sorted_len.begin());
+            };
+            if (const char* e = getenv("TGX_LONG_THRESHOLD")) {
+                const uint64_t thr = (uint64_t)std::max(0ll, atoll(e));
+                if (thr) n_long4 = count_ge(thr);
+            } else {
+                const double N = (double)c->n_bytes;
+                auto cost = [&](uint64_t k) {
+                    const double bytes_long = k ? (double)c->h_sorted_cum[k - 1] : 0.0;
+                    // (with pools: 32 KiB of table + 32 KiB of pools leave room for ONE block per CU: ~20 GB/s measured)
+                    const double t6 = k ? std::max((double)c->h_sorted_len[0] * 0.0369e-6, bytes_long / (m->has_cold ? 20e9 : 55e9)) + 40e-6 : 0.0;
+                    const double rest_max = k < c->n_samples ? (double)c->h_sorted_len[k] : 0.0;
+                    return t6 + cost4(N - bytes_long, rest_max, nullptr);
+                };
+                double best = cost(0);
+                for (uint64_t thr = 1024; thr <= c->max_len; thr *= 2) {
+                    const uint64_t k = count_ge(thr);
+                    const double ck = cost(k);
+                    if (k && ck < best * 0.9) {
+                        best = ck;
+                        n_long4 = k;
+                    }
+                }
+            }
+        }
+        m->last_long_samples = n_long4;
+        m->last_redo_samples = 0;
+        uint64_t n_redo4 = 0;
+        if (n_long4) {
+            tgx::Encode5Params q{};
+            q.trie8 = m->d_trie8;
+            q.cold_scores = m->d_cold_scores;
+            q.hot = m->d_hot;
+            q.root_base = m->root_base8;
+            q.n_hot = m->n_hot;
+            q.pool_entries = m->has_cold ? tgx::encode6_max_pool_entries(m->n_hot) : 0u;
+            if (const char* e = getenv("TGX_E5_POOL")) q.pool_entries = std::min<uint32_t>(q.pool_entries, (uint32_t)std::max(4, atoi(e)));
+            q.redo_count = m->d_ctrl + 6;
+            q.redo_list = c->d_counts;  // free until the trace writes the token counts
+            HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
+            tgx::EncodeParams p6 = p;
+            p6.n_samples = n_long4;
+            const uint32_t blocks6 = (uint32_t)std::min<uint64_t>((n_long4 + 3) / 4, (uint64_t)m->num_cus * 2);
+            time_begin(m, "encode6_kernel");
+            HIP_TRY(tgx::launch_encode6(p6, q, m->has_cold, blocks6, m->stream));
+            time_end(m);
+            if (m->has_cold) {
+                unsigned long long nr = 0;
+                HIP_TRY(hipMemcpyAsync(&nr, m->d_ctrl + 6, 8, hipMemcpyDeviceToHost, m->stream));
+                HIP_TRY(hipStreamSynchronize(m->stream));
+                if (nr > n_long4) return fail(TGX_ERR_DEVICE, "redo list longer than the batch");
+                n_redo4 = nr;
+                m->last_redo_samples = nr;
+            }
+            HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode4_kernel
+            p.order = c->d_order + n_long4;
+            p.n_samples = c->n_samples - n_long4;
+        }
+        {
+            const double rest_bytes = (double)c->n_bytes - (n_long4 ? (double)c->h_sorted_cum[n_long4 - 1] : 0.0);
+            const double rest_max = n_long4 < c->n_samples ? (double)c->h_sorted_len[n_long4] : 0.0;
+            cost4(rest_bytes, rest_max, &ppl);
         }
         if (const char* e = getenv("TGX_PPL")) {
             const int v = atoi(e);
@@ -599,7 +674,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks4 = (uint32_t)std::max<uint64_t>(
-            1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
+            1, std::min<uint64_t>((p.n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
         unsigned long long* d_stamps = nullptr;
         const size_t n_stamp_waves = (size_t)blocks4 * (size_t)waves;
         if (const char* e = getenv("TGX_STAMPS")) {
@@ -641,6 +716,19 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             (void)hipFree(d_stamps);
             p.stamps = nullptr;
         }
+        if (n_redo4) {  // long samples whose ring slot ran out of pool entries: few, so their serial chains are the cost
+            tgx::EncodeParams r4 = p;
+            r4.order = c->d_counts;
+            r4.n_samples = n_redo4;
+            r4.stamps = nullptr;
+            HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
+            const uint32_t b4 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_redo4 + 19) / 20, (uint64_t)m->num_cus));
+            time_begin(m, "encode4_kernel");
+            HIP_TRY(tgx::launch_encode4(r4, 4, 5, b4, false, m->stream));
+            time_end(m);
+        }
+        p.order = c->d_order;
+        p.n_samples = c->n_samples;
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
         unsigned long long* d_tstamps = nullptr;
