@@ -357,7 +357,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     // its table (generate-style vocabularies: scores are logs of integer counts).  A vocabulary with more values
     // than that (after an M-step every token has its own) stays on encode4_kernel: the pools that would serve
     // its cold values (a third of the matches at 32 000 entries) cost what the 16-byte records cost, and every
-    // overflow sends a sample to a second pass (profiles/r02: cold_*).  TGX_PATH=rows4 / rows5 force either
+    // overflow sends a sample to a second pass (profiles/r02: w_cold_vocabulary_*).  TGX_PATH=rows4 / rows5 force either
     // kernel (A/B timing, tests of both paths).
     const bool use5 = use4 && m->have_trie8 && !(force && strcmp(force, "rows4") == 0) &&
                       (!m->has_cold || (force && strcmp(force, "rows5") == 0));
