@@ -160,6 +160,6 @@ hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted,
 hipError_t launch_encode4l(const EncodeParams& p, uint32_t num_cus, hipStream_t stream);  // encode4l.hip
 hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_scan(uint32_t* counts, uint64_t* offsets, uint64_t n, void* temp, size_t temp_bytes, hipStream_t stream);
-hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream);
+hipError_t launch_compact(const CompactParams& p, uint32_t blocks, bool rows, hipStream_t stream);
 
 }  // namespace tgx

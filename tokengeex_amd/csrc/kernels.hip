@@ -647,12 +647,16 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t* __res
     if (tid == 0) offsets[n] = carry_s;
 }
 
-// tmp (right-aligned per sample) -> ids (packed), one wave per sample.
+// tmp (right-aligned per sample) -> ids (packed).  One wave per sample, or — ROWS: batches of short samples, a few
+// dozen ids each — one 16-lane row per sample (four samples per wave; neighbours in the longest-first order have
+// similar lengths).
+template <bool ROWS>
 __global__ __launch_bounds__(256) void compact_kernel(CompactParams P) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_waves = gridDim.x * 4u;
-    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
-    for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
+    const uint32_t sub = ROWS ? (lane & 15u) : lane, width = ROWS ? 16u : 64u;
+    const uint64_t n_units = (uint64_t)gridDim.x * 4u * (ROWS ? 4u : 1u);
+    const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+    for (uint64_t k = ROWS ? (uint64_t)wave_id * 4u + (lane >> 4) : (uint64_t)wave_id; k < P.n_samples; k += n_units) {
         const uint32_t s = P.order[k];
         const uint64_t end = P.offs[s + 1];
         const uint64_t o0 = P.out_offs[s];
@@ -662,9 +666,9 @@ __global__ __launch_bounds__(256) void compact_kernel(CompactParams P) {
         // 16 bytes per lane (neither side is 16-byte aligned: unaligned dwordx4), the last 0..3 ids one by one
         struct __attribute__((packed, aligned(4))) Ids4 { uint32_t w[4]; };
         const uint32_t body = cnt & ~3u;
-        for (uint32_t i = lane * 4u; i < body; i += 256u)
+        for (uint32_t i = sub * 4u; i < body; i += width * 4u)
             *reinterpret_cast<Ids4*>(dst + i) = *reinterpret_cast<const Ids4*>(src + i);
-        if (body + lane < cnt) dst[body + lane] = src[body + lane];
+        if (body + sub < cnt) dst[body + sub] = src[body + sub];
     }
 }
 
@@ -780,8 +784,11 @@ hipError_t launch_scan(uint32_t* counts, uint64_t* offsets, uint64_t n, void* te
     return rocprim::exclusive_scan(temp, temp_bytes, in, offsets, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), stream);
 }
 
-hipError_t launch_compact(const CompactParams& p, uint32_t blocks, hipStream_t stream) {
-    hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, stream, p);
+hipError_t launch_compact(const CompactParams& p, uint32_t blocks, bool rows, hipStream_t stream) {
+    if (rows)
+        hipLaunchKernelGGL(compact_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL(compact_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

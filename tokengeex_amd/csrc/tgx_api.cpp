@@ -1277,8 +1277,11 @@ static tgx_status encode_corpus_locked(tgx_model* m, tgx_corpus* c, double dropo
     cp.out_offs = r->d_offs;
     cp.ids = r->d_ids;
     time_begin(m, "compact_kernel");
-    uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((S + 3) / 4, (uint64_t)m->num_cus * 8));
-    if (tgx::launch_compact(cp, blocks, m->stream) != hipSuccess)
+    // short samples (fewer than 128 ids on average): a 16-lane row per sample instead of a wave
+    const bool rows = S && r->n_tokens / S < 128;
+    const uint64_t units = rows ? 16 : 4;  // samples per block and round
+    uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((S + units - 1) / units, (uint64_t)m->num_cus * 8));
+    if (tgx::launch_compact(cp, blocks, rows, m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "compact launch failed"));
     time_end(m);
     if (hipStreamSynchronize(m->stream) != hipSuccess)
