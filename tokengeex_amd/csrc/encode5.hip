@@ -297,6 +297,9 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
         }
 
         // ---- relax: a lane's 16 match indices are 32 contiguous bytes; the scores come from the table
+        // (the walks — latency chains — issue ahead of the relaxing waves of their SIMD, which fill the gaps:
+        // 11.28 -> 11.06 ms; the other way round 11.23 -> 11.53; TGX_FLAGS=32 with TGX_DEBUG=1 switches it off)
+        if (!(P.flags & 32u)) __builtin_amdgcn_s_setprio(0);
         uint32_t fin[PPL];
         bool reached[PPL];
 #pragma unroll
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             reached[g] = fhi != 0xFFF00000u;
         }
         __builtin_amdgcn_wave_barrier();
+        if (!(P.flags & 32u)) __builtin_amdgcn_s_setprio(2);
         E5_STAMP(3)  // relax
 
         // ---- back-pointer bytes (encode4_kernel's packed, permuted layout), next block
