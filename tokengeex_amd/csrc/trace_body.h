@@ -48,7 +48,11 @@ __device__ __forceinline__ void trace_body(const EncodeParams& P, uint2* ring) {
     // Static round-robin over the longest-first order.  (Claiming samples from a global counter, as
     // encode4_kernel does per row, gained nothing here on 64 KiB samples and cost 2-5x on corpora of
     // short samples: one atomic per sample on one address serialises the waves.)
-    for (uint64_t k = wave_id; k < P.n_samples; k += n_waves) {
+    // Rounds alternate direction (wave w takes w, 2W - 1 - w, 2W + w, ...): the order descends by length, so a
+    // plain stride gives wave 0 the longest sample of every round.
+    for (uint64_t base = 0, rnd = 0; base < P.n_samples; base += n_waves, ++rnd) {
+        const uint64_t k = base + ((rnd & 1u) ? (uint64_t)(n_waves - 1u - wave_id) : (uint64_t)wave_id);
+        if (k >= P.n_samples) continue;
         const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.order[k]);
         const uint64_t beg = first_u64(P.offs[s]);
         const uint32_t n = (uint32_t)(first_u64(P.offs[s + 1]) - beg);
