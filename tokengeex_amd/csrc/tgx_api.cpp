@@ -209,6 +209,7 @@ struct tgx_model {
     double* d_hot = nullptr;
     uint32_t n_hot = 0, root_base8 = 0;
     bool have_trie8 = false, has_cold = false;
+    bool encode_tables_ready = false;  // tokhash / trie8 built and uploaded (ensure_encode_tables)
     double hot_coverage = 0.0;
     int estep_blocks_per_cu = 0;
     KernelTime timed[kMaxTimed] = {};
@@ -850,6 +851,51 @@ void tgx_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
+// Tables that only the encode path reads (built at creation, or at the first encode of a model created with
+// TGX_MODEL_FOR_ESTEP: prune builds two such models per iteration and never encodes with them).  Caller holds
+// m->mu (or is the creating thread).
+static tgx_status ensure_encode_tables(tgx_model* m) {
+    if (m->encode_tables_ready) return TGX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->lm <= 32 && m->scores_finite) {
+        tgx::build_tok_hash(m->vocab_bytes.data(), m->vocab_offs.data(), m->vocab_size, &m->tokhash);
+        if (m->tokhash.ok) {
+            const size_t hb = m->tokhash.slots.size() * sizeof(tgx::TokHashEntry);
+            HIP_TRY(hipMalloc(&m->d_tokhash, hb));
+            HIP_TRY(hipMemcpyAsync(m->d_tokhash, m->tokhash.slots.data(), hb, hipMemcpyHostToDevice, m->stream));
+        }
+    }
+    if (m->lm <= 16 && m->scores_finite && m->d_tokhash && m->flat.table.size() < (1u << 23)) {
+        tgx::Trie8 t8;
+        uint32_t max_hot = kE5MaxHot;
+        if (const char* e = getenv("TGX_E5_MAX_HOT")) {  // tests: a small table forces the cold-value paths
+            const int v = atoi(e);
+            if (v >= 0 && v <= (int)kE5MaxHot) max_hot = (uint32_t)v;
+        }
+        tgx::build_trie8(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), max_hot, kE5MaxHotCold, &t8);
+        const size_t ns = t8.rec.size();
+        HIP_TRY(hipMalloc(&m->d_trie8, ns * sizeof(tgx::Trie8Rec)));
+        HIP_TRY(hipMalloc((void**)&m->d_cold_scores, ns * 8));
+        HIP_TRY(hipMalloc((void**)&m->d_hot, std::max<size_t>(8, t8.hot.size() * 8)));
+        HIP_TRY(hipMemcpy(m->d_trie8, t8.rec.data(), ns * sizeof(tgx::Trie8Rec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(m->d_cold_scores, t8.cold_scores.data(), ns * 8, hipMemcpyHostToDevice));
+        if (!t8.hot.empty()) HIP_TRY(hipMemcpy(m->d_hot, t8.hot.data(), t8.hot.size() * 8, hipMemcpyHostToDevice));
+        m->n_hot = (uint32_t)t8.hot.size();
+        m->root_base8 = t8.root_base;
+        m->hot_coverage = t8.hot_coverage;
+        m->has_cold = false;
+        for (const tgx::Trie8Rec& q : t8.rec)
+            if (q.sref & tgx::kTrie8Cold) {
+                m->has_cold = true;
+                break;
+            }
+        m->have_trie8 = true;
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->encode_tables_ready = true;
+    return TGX_OK;
+}
+
 tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                             uint32_t vocab_size, int device, tgx_model** out) {
     return tgx_model_create_ex(bytes, offs, scores, vocab_size, device, 0, out);
@@ -931,39 +977,11 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
     HIP_TRY_M(hipMalloc(&m->d_trie, tbytes));
     HIP_TRY_M(hipMalloc((void**)&m->d_tokid, m->flat.tokid.size() * 4));
     HIP_TRY_M(hipMalloc((void**)&m->d_ctrl, 64));
-    if (m->lm <= 32 && m->scores_finite) {
-        tgx::build_tok_hash(bytes, vocab_size ? offs : zero_offs, vocab_size, &m->tokhash);
-        if (m->tokhash.ok) {
-            const size_t hb = m->tokhash.slots.size() * sizeof(tgx::TokHashEntry);
-            HIP_TRY_M(hipMalloc(&m->d_tokhash, hb));
-            HIP_TRY_M(hipMemcpyAsync(m->d_tokhash, m->tokhash.slots.data(), hb, hipMemcpyHostToDevice, m->stream));
-        }
-    }
-    if (m->lm <= 16 && m->scores_finite && m->d_tokhash && m->flat.table.size() < (1u << 23)) {
-        tgx::Trie8 t8;
-        uint32_t max_hot = kE5MaxHot;
-        if (const char* e = getenv("TGX_E5_MAX_HOT")) {  // tests: a small table forces the cold-value paths
-            const int v = atoi(e);
-            if (v >= 0 && v <= (int)kE5MaxHot) max_hot = (uint32_t)v;
-        }
-        tgx::build_trie8(m->flat, vocab_size ? offs : zero_offs, scores, max_hot, kE5MaxHotCold, &t8);
-        const size_t ns = t8.rec.size();
-        HIP_TRY_M(hipMalloc(&m->d_trie8, ns * sizeof(tgx::Trie8Rec)));
-        HIP_TRY_M(hipMalloc((void**)&m->d_cold_scores, ns * 8));
-        HIP_TRY_M(hipMalloc((void**)&m->d_hot, std::max<size_t>(8, t8.hot.size() * 8)));
-        HIP_TRY_M(hipMemcpy(m->d_trie8, t8.rec.data(), ns * sizeof(tgx::Trie8Rec), hipMemcpyHostToDevice));
-        HIP_TRY_M(hipMemcpy(m->d_cold_scores, t8.cold_scores.data(), ns * 8, hipMemcpyHostToDevice));
-        if (!t8.hot.empty()) HIP_TRY_M(hipMemcpy(m->d_hot, t8.hot.data(), t8.hot.size() * 8, hipMemcpyHostToDevice));
-        m->n_hot = (uint32_t)t8.hot.size();
-        m->root_base8 = t8.root_base;
-        m->hot_coverage = t8.hot_coverage;
-        m->has_cold = false;
-        for (const tgx::Trie8Rec& q : t8.rec)
-            if (q.sref & tgx::kTrie8Cold) {
-                m->has_cold = true;
-                break;
-            }
-        m->have_trie8 = true;
+    // the tables only encode needs (bytes -> id table of the trace, 8-byte records and score table of
+    // encode5_kernel): now, unless the model is created for E-step passes — then at its first encode
+    if (!(flags & TGX_MODEL_FOR_ESTEP)) {
+        const tgx_status est = ensure_encode_tables(m);
+        if (est != TGX_OK) return cleanup(est);
     }
     HIP_TRY_M(hipHostMalloc((void**)&m->h_ctrl, 64, hipHostMallocDefault));
     HIP_TRY_M(hipMemcpyAsync(m->d_trie, m->flat.table.data(), tbytes, hipMemcpyHostToDevice, m->stream));
@@ -1232,6 +1250,10 @@ uint64_t tgx_corpus_num_bytes(const tgx_corpus* c) { return c ? c->n_bytes : 0; 
 static tgx_status encode_corpus_locked(tgx_model* m, tgx_corpus* c, double dropout, uint64_t seed,
                                        tgx_result** out) {
     HIP_TRY(hipSetDevice(m->device));
+    {
+        const tgx_status est = ensure_encode_tables(m);
+        if (est != TGX_OK) return est;
+    }
     m->n_timed = 0;
     const uint64_t S = c->n_samples;
 
