@@ -167,8 +167,43 @@ def ptr(a: np.ndarray | None):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class Packed:
+    """A list of byte strings kept in the ABI's batch format (flat bytes + offsets), with subsets taken without a
+    Python loop: what the prune driver carries its vocabulary in between passes (500 000 tokens: a list
+    comprehension plus pack() per model cost as much as the native trie build)."""
+
+    __slots__ = ("flat", "offs")
+
+    def __init__(self, flat: np.ndarray, offs: np.ndarray):
+        self.flat, self.offs = flat, offs
+
+    @classmethod
+    def of(cls, items) -> "Packed":
+        return items if isinstance(items, Packed) else cls(*pack(items))
+
+    def __len__(self) -> int:
+        return int(self.offs.shape[0]) - 1
+
+    def take(self, idx) -> "Packed":
+        idx = np.asarray(idx, dtype=np.int64)
+        beg, end = self.offs[:-1][idx].astype(np.int64), self.offs[1:][idx].astype(np.int64)
+        lens = end - beg
+        offs = np.zeros(idx.shape[0] + 1, np.uint64)
+        np.cumsum(lens, out=offs[1:])
+        total = int(offs[-1])
+        # byte j of the output comes from beg[i] + (j - offs[i]) of the token i it belongs to
+        src = np.repeat(beg - offs[:-1].astype(np.int64), lens) + np.arange(total, dtype=np.int64)
+        return Packed(self.flat[src] if total else np.zeros(0, np.uint8), offs)
+
+    def tolist(self) -> list[bytes]:
+        raw, o = self.flat.tobytes(), self.offs.tolist()
+        return [raw[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+
+
 def pack(items) -> tuple[np.ndarray, np.ndarray]:
-    """list[bytes] -> (uint8 flat, uint64 offsets[len+1]) — the ABI's batch format."""
+    """list[bytes] (or a Packed) -> (uint8 flat, uint64 offsets[len+1]) — the ABI's batch format."""
+    if isinstance(items, Packed):
+        return items.flat, items.offs
     offs = np.zeros(len(items) + 1, dtype=np.uint64)
     if len(items):
         np.cumsum(np.fromiter((len(t) for t in items), dtype=np.uint64, count=len(items)), out=offs[1:])

@@ -38,8 +38,20 @@ class ModelVocabularyPruner:
         self.timings: list[dict] = []
 
     # -- one pass each ------------------------------------------------------------------
-    def _model(self, vocab: Vocab, for_estep: bool = False) -> _lib.NativeModel:
-        return _lib.NativeModel([t[0] for t in vocab], [t[1] for t in vocab], self.device, for_estep=for_estep)
+    # The public methods take and return ScoredToken lists as the reference's do; the loop below carries the
+    # vocabulary as (Packed token bytes, scores f64[V], keep u8[V]) so that nothing iterates over V in Python.
+    @staticmethod
+    def _arrays(vocab: Vocab):
+        return (_lib.Packed.of([t[0] for t in vocab]), np.array([t[1] for t in vocab], np.float64),
+                np.array([1 if t[2] else 0 for t in vocab], np.uint8))
+
+    @staticmethod
+    def _vocab(toks: "_lib.Packed", scores: np.ndarray, keep: np.ndarray) -> Vocab:
+        return list(zip(toks.tolist(), scores.tolist(), (keep != 0).tolist()))
+
+    def _model(self, vocab, for_estep: bool = False) -> _lib.NativeModel:
+        toks, scores = (vocab[0], vocab[1]) if isinstance(vocab, tuple) else ([t[0] for t in vocab], [t[1] for t in vocab])
+        return _lib.NativeModel(toks, scores, self.device, for_estep=for_estep)
 
     def run_e_step(self, model: _lib.NativeModel, corpus: _lib.NativeCorpus) -> np.ndarray:
         """src/prune.rs:64-120 (81 920-byte snippets; z must be normal)."""
@@ -48,54 +60,61 @@ class ModelVocabularyPruner:
         return tdist.allreduce_vector(expected, self.dist, self.reduce_device)
 
     @staticmethod
+    def _m_step(arrays, expected: np.ndarray):
+        toks, _, keep = arrays
+        idx, scores = _lib.prune_m_step(expected, keep)
+        return toks.take(idx), np.asarray(scores, np.float64), keep[np.asarray(idx, np.int64)]
+
+    @staticmethod
     def run_m_step(vocab: Vocab, expected: np.ndarray) -> Vocab:
         """src/prune.rs:124-170."""
-        keep = np.array([1 if t[2] else 0 for t in vocab], np.uint8)
-        idx, scores = _lib.prune_m_step(expected, keep)
-        return [(vocab[int(i)][0], float(s), vocab[int(i)][2]) for i, s in zip(idx, scores)]
+        return ModelVocabularyPruner._vocab(*ModelVocabularyPruner._m_step(ModelVocabularyPruner._arrays(vocab), expected))
+
+    def _prune_arrays(self, arrays, model: _lib.NativeModel, corpus: _lib.NativeCorpus):
+        toks, scores, keep = arrays
+        V = len(toks)
+        pruned_size = max(int(V * self.shrink_factor), self.vocab_size)
+        trie = _lib.FlatTrie(toks, scores)
+        always_keep, alt_offs, alt_ids = trie.prune_alternatives(toks, scores)
+        freq = tdist.allreduce_vector(model.count_tokens(corpus), self.dist, self.reduce_device)
+        n_samples = tdist.allreduce_scalar(corpus.num_samples, self.dist, self.reduce_device)
+        out = np.asarray(_lib.prune_select(freq, keep, always_keep, alt_offs, alt_ids, scores, n_samples, pruned_size), np.int64)
+        return toks.take(out), scores[out], keep[out]
 
     def prune_vocab(self, vocab: Vocab, model: _lib.NativeModel, corpus: _lib.NativeCorpus) -> Vocab:
         """src/prune.rs:173-319."""
-        V = len(vocab)
-        pruned_size = max(int(V * self.shrink_factor), self.vocab_size)
-        tokens = [t[0] for t in vocab]
-        scores = np.array([t[1] for t in vocab], np.float64)
-        keep = np.array([1 if t[2] else 0 for t in vocab], np.uint8)
-        trie = _lib.FlatTrie(tokens, scores)
-        always_keep, alt_offs, alt_ids = trie.prune_alternatives(tokens, scores)
-        freq = tdist.allreduce_vector(model.count_tokens(corpus), self.dist, self.reduce_device)
-        n_samples = tdist.allreduce_scalar(corpus.num_samples, self.dist, self.reduce_device)
-        out = _lib.prune_select(freq, keep, always_keep, alt_offs, alt_ids, scores, n_samples, pruned_size)
-        return [vocab[int(i)] for i in out]
+        return self._vocab(*self._prune_arrays(self._arrays(vocab), model, corpus))
 
     # -- the loop -----------------------------------------------------------------------
     def prune(self, vocab: Vocab, flat: np.ndarray, offs: np.ndarray) -> Vocab:
         """prune(&mut model, samples) — src/prune.rs:23-57.  `flat`/`offs`: packed samples."""
         corpus = _lib.NativeCorpus(flat, offs, self.device)
+        arrays = self._arrays(vocab)
         try:
-            while len(vocab) > self.vocab_size:
-                rec = {"from": len(vocab), "e_step_s": 0.0, "m_step_s": 0.0}
+            while len(arrays[0]) > self.vocab_size:
+                rec = {"from": len(arrays[0]), "e_step_s": 0.0, "m_step_s": 0.0}
                 for sub in range(self.em_subiters):
-                    model = self._model(vocab, for_estep=True)
+                    model = self._model(arrays, for_estep=True)
                     t0 = time.perf_counter()
                     expected = self.run_e_step(model, corpus)
                     t1 = time.perf_counter()
-                    new_vocab = self.run_m_step(vocab, expected)
+                    new_arrays = self._m_step(arrays, expected)
                     t2 = time.perf_counter()
                     rec["e_step_s"] += t1 - t0
                     rec["m_step_s"] += t2 - t1
-                    self.log(f"EM subiter {sub + 1}/{self.em_subiters} vocab_size={len(vocab)} "
-                             f"alternative_vocab_size={len(new_vocab)}")
+                    self.log(f"EM subiter {sub + 1}/{self.em_subiters} vocab_size={len(arrays[0])} "
+                             f"alternative_vocab_size={len(new_arrays[0])}")
                     model.free()
-                    vocab = new_vocab
-                model = self._model(vocab)
+                    arrays = new_arrays
+                model = self._model(arrays)
                 t0 = time.perf_counter()
-                vocab = self.prune_vocab(vocab, model, corpus)
+                arrays = self._prune_arrays(arrays, model, corpus)
                 rec["prune_vocab_s"] = time.perf_counter() - t0
-                rec["to"] = len(vocab)
+                rec["to"] = len(arrays[0])
                 model.free()
                 self.timings.append(rec)
                 self.log(f"pruned vocabulary from={rec['from']} to={rec['to']}")
+            vocab = self._vocab(*arrays)
         finally:
             corpus.free()
         return vocab
