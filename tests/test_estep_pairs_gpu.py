@@ -180,6 +180,49 @@ def test_log_domain_kernels_hold_the_tightest_tolerance_they_meet(monkeypatch):
         assert abs(gz - wz) <= 1e-12 * abs(wz)
 
 
+@pytest.mark.parametrize("max_len", [24, 32])
+def test_estep_with_tokens_of_17_to_32_bytes(monkeypatch, max_len):
+    """Vocabularies after `merge` (src/merge.rs: tokens of up to 24 bytes by default): the linear-domain rows4
+    kernels in their long-token builds (a second accumulator per lane + a per-wave overflow list, estep4l.hip)
+    against the oracle, with and without dropout, and against the generic kernel."""
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 6000, max_len, seed_offset=31)
+    assert max(len(t) for t in toks) > 16
+    nat, ora = _pair(toks, scores)
+    corpus = tgx.NativeCorpus(flat, offs)
+    for snip, dropout in ((20000, 0.0), (4096, 0.1), (81920, 0.0)):
+        got, gz = nat.estep(corpus, snip, dropout, 5)
+        kt = nat.last_kernel_times()
+        assert "estep4l_fwd_kernel" in kt and "estep4l_bwd_kernel" in kt and "estep_kernel" not in kt, kt
+        st, want, wz, _ = ora.estep_flat(flat, offs, snip, dropout, 5, threads=8)
+        assert st == orc.OK
+        np.testing.assert_allclose(got, want, rtol=rtol_for(snip), atol=ATOL)
+        assert np.array_equal(got != 0, want != 0)
+        assert abs(gz - wz) <= 1e-12 * abs(wz)
+    monkeypatch.setenv("TGX_PATH", "fused")
+    gen, zg = nat.estep(corpus, 20000, 0.0, 5)
+    assert "estep_kernel" in nat.last_kernel_times()
+    monkeypatch.delenv("TGX_PATH")
+    lin, zl = nat.estep(corpus, 20000, 0.0, 5)
+    np.testing.assert_allclose(lin, gen, rtol=rtol_for(20000), atol=ATOL)
+
+
+def test_estep_long_token_overflow_list_falls_back_to_the_generic_kernel():
+    """A run of blanks under a vocabulary with a blank token of every length up to 32: every position has sixteen
+    long matches, the per-wave overflow list (62 entries per block) fills up, and the pass is redone by the
+    generic kernel — same expected counts as the oracle's."""
+    toks = [bytes([b]) for b in range(256)] + [b" " * k for k in range(2, 33)] + [b"ab", b"abc"]
+    scores = np.concatenate([np.full(256, -6.0), -2.0 - 0.05 * np.arange(31), [-4.0, -5.0]])
+    nat, ora = _pair(toks, scores)
+    texts = [b" " * 700 + b"abc" * 20, b"ab" * 50 + b" " * 300, b"x"]
+    flat, offs = tgx.pack(texts)
+    got, gz = nat.estep(tgx.NativeCorpus(flat, offs), 81920)
+    assert "estep_kernel" in nat.last_kernel_times()
+    st, want, wz, _ = ora.estep_flat(flat, offs, 81920, threads=2)
+    assert st == orc.OK
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=ATOL)
+    assert abs(gz - wz) <= 1e-12 * abs(wz)
+
+
 def test_estep_falls_back_to_log_domain_when_a_position_has_no_incoming_token():
     """A text byte that is no token leaves a position without an incoming token (lattice.rs:255: it then
     counts as log-probability 0.0), which the linear-domain kernels cannot express: their forward kernel

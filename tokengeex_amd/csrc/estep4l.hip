@@ -46,6 +46,27 @@ __device__ __forceinline__ int row_max_exponent(double acc) {
     return e;
 }
 
+// ---- tokens of 17..32 bytes (vocabularies after `merge`): LONG = true builds ---------------------------------
+// Such tokens are rare matches, so the kernels keep their 16-column structure and add, per lane, a second
+// accumulator `far` for the position 17..32 ahead (the scheme of encode4l_kernel; sums commute, so no order
+// has to be kept here): the walk goes on past depth 16 only where the trie continues, a match of 17..32 bytes
+// goes to a per-wave overflow list in LDS instead of the match buffer, lane U restarts from `far` at step U, and
+// after the 16 steps of a block the list is applied: (value of the source position) x w into `acc` (target
+// 17..31 ahead of the block's first position) or `far` (32..47).  A list that fills up raises range_flag = 2
+// and the host redoes the pass with the generic kernel.
+constexpr uint32_t kE4LOvfCap = 62;                            // entries per wave and block
+constexpr uint32_t kE4LOvfBytes = 16u + kE4LOvfCap * 16u;      // {pad} + entries {lane, len | slot << 8 (unused fwd), f64 w}
+
+template <int U>
+__device__ __forceinline__ void e4l_fwd_step_long(double sv, double& acc, double& far, double& fin) {
+    constexpr uint64_t MU = kRowLane0 << U;
+    fin = sel_f64(MU, acc, fin);
+    const double best = row_bcast_f64<U>(acc);
+    const double cand = best * sv;
+    acc = sel_f64(MU, far, acc) + cand;      // lane U restarts from the long contributions to position p0 + U + 16
+    far = sel_f64(MU, 0.0, far);             // its `far` now stands for position p0 + U + 32
+}
+
 template <int U>
 __device__ __forceinline__ void e4l_fwd_step(double sv, double& acc, double& fin) {
     constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
@@ -83,12 +104,35 @@ __device__ __forceinline__ void e4l_bwd_step(double sv, uint32_t hv, double c_cu
     acc = sel_f64(MU, cand, acc + cand);
 }
 
+template <int U>
+__device__ __forceinline__ void e4l_bwd_step_long(double sv, uint32_t hv, double c_cur, double c_nxt, int e_cur, int e_nxt,
+                                                  int eb, double* __restrict__ expected_slot, double2* hot, uint32_t n_hot, bool cold_ok,
+                                                  double& acc, double& far, double& fin) {
+    constexpr uint64_t MU = kRowLane0 << U;
+    constexpr uint64_t WRAPPED = (uint64_t)((1u << (U + 1)) - 1u) * kRowLane0;
+    fin = sel_f64(MU, acc, fin);                // b[q] of the source position is final now (the long matches use it)
+    const double best = row_bcast_f64<U>(acc);
+    const double cand = best * sv;
+    const double c = sel_f64(WRAPPED, c_nxt, c_cur);
+    const int e = (int)sel_u32(WRAPPED, (uint32_t)e_nxt, (uint32_t)e_cur);
+    if (sv != 0.0) {
+        const double mg = ldexp(cand * c, e + eb);
+        if (hv < n_hot)
+            atomicAdd(&hot[hv].x, mg);
+        else if (cold_ok)
+            atomicAdd(&expected_slot[hv], mg);
+    }
+    acc = sel_f64(MU, far, acc) + cand;         // lane U restarts from the long contributions to its next position
+    far = sel_f64(MU, 0.0, far);
+}
+
 // PPL = positions per lane and trip (1, 2, 4): a row advances 16 * PPL positions per trip of the dependent
 // gather chain.  The relaxation is cheap here (one multiply-add per step), so more positions per lane shorten
 // the serial chain of a long snippet almost proportionally, at the price of LDS (8 KiB * PPL per wave
 // forward, 12 KiB * PPL backward) and with it waves per CU; the host picks PPL from the shape of the pass.
-template <bool DROPOUT, int PPL>
+template <bool DROPOUT, int PPL, bool LONG>
 __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
+    static_assert(!LONG || PPL == 1, "the long-token build runs one position per lane");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
     constexpr uint32_t SPAN = 16u * PPL;
@@ -97,11 +141,14 @@ __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
     const uint32_t wave = threadIdx.x >> 6;
     const uint4* __restrict__ trie = reinterpret_cast<const uint4*>(P.trie_fwd);  // records carry w = exp(score)
     double* sc = reinterpret_cast<double*>(smem + (size_t)wave * (PPL * kE4LEntries * 8u));
+    // LONG: this wave's overflow list, behind the match buffers of the block's waves
+    unsigned char* ovf = smem + (size_t)(blockDim.x >> 6) * (PPL * kE4LEntries * 8u) + (size_t)wave * kE4LOvfBytes;
+    constexpr uint32_t LMX = LONG ? 32u : 16u;  // longest token
 
     uint32_t s = 0, n = 0, p0 = 0, smp = 0;
     uint64_t beg = 0, sbase = 0, ebase = 0;
     bool live = false, need_new = true;
-    double acc = 0.0;
+    double acc = 0.0, far = 0.0;
     int erow = 0;  // alpha_true = acc * 2^erow for every accumulator of the row
     double zsum = 0.0;
 
@@ -121,6 +168,7 @@ __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
             }
             p0 = 0;
             acc = (l == 0u) ? 1.0 : 0.0;  // BOS: alpha = 0 in the log domain (lattice.rs:96-101, 267)
+            far = 0.0;
             erow = 0;
         }
         need_new = false;
@@ -150,7 +198,7 @@ __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
         for (int g = 0; g < PPL; ++g) {
             pg[g] = p0 + 16u * g + l;
             const uint32_t rem = (live && pg[g] < n) ? (n - pg[g]) : 0u;
-            maxd[g] = rem < LM ? rem : LM;
+            maxd[g] = rem < LMX ? rem : LMX;
             cur[g] = 0;
             base[g] = P.root_fwd;
             alive[g] = maxd[g] > 0;
@@ -190,6 +238,43 @@ __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
                 }
             }
         }
+        uint32_t n_ovf = 0;  // wave-uniform: overflow entries of this block
+        if (LONG) {
+            // walks that are still alive after 16 bytes (the trie continues: a token of 17..32 bytes may follow)
+            bool more = alive[0] && maxd[0] > 16u;
+            if (__builtin_amdgcn_ballot_w64(more) != 0) {
+                uint32_t b2[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b2[q] = __builtin_amdgcn_alignbyte(wp[4 + q + 1], wp[4 + q], sh);  // text bytes 16..31
+                for (uint32_t d = 16; d < 32u; ++d) {
+                    more = more && d < maxd[0];
+                    if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+                    const uint32_t word = (d & 8u) ? ((d & 4u) ? b2[3] : b2[2]) : ((d & 4u) ? b2[1] : b2[0]);
+                    const uint32_t c = (word >> ((d & 3u) * 8u)) & 0xFFu;
+                    const uint32_t t = more ? (base[0] ^ c) : 0u;
+                    const uint4 rec = load_rec(trie, t);
+                    more = more && rec.x == cur[0];
+                    bool term = more && (rec.y >> 31) != 0u;
+                    if (more) {
+                        cur[0] = t;
+                        base[0] = rec.y & 0x7FFFFFFFu;
+                    }
+                    if (DROPOUT) {
+                        if (term) term = !(dropout_u01(P.seed, smp, sbase + pg[0], d + 1u) < P.dropout);
+                    }
+                    const uint64_t tm = __builtin_amdgcn_ballot_w64(term);
+                    if (tm != 0) {  // wave-uniform
+                        const uint32_t e = n_ovf + __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u));
+                        n_ovf += (uint32_t)__builtin_popcountll(tm);
+                        if (term && e < kE4LOvfCap) *reinterpret_cast<uint4*>(ovf + 16u + e * 16u) = make_uint4(lane, d + 1u, rec.z, rec.w);
+                    }
+                }
+                if (n_ovf > kE4LOvfCap) {  // the pass goes to the generic kernel
+                    atomicMax(P.range_flag, 2ULL);
+                    n_ovf = kE4LOvfCap;
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
 
         // ---- forward recursion: 16 static steps per group of 16 positions, then the row is rescaled (its
@@ -202,22 +287,53 @@ __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
             double sv[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) sv[u] = scr[u * 16];
-            e4l_fwd_step<0>(sv[0], acc, fin);
-            e4l_fwd_step<1>(sv[1], acc, fin);
-            e4l_fwd_step<2>(sv[2], acc, fin);
-            e4l_fwd_step<3>(sv[3], acc, fin);
-            e4l_fwd_step<4>(sv[4], acc, fin);
-            e4l_fwd_step<5>(sv[5], acc, fin);
-            e4l_fwd_step<6>(sv[6], acc, fin);
-            e4l_fwd_step<7>(sv[7], acc, fin);
-            e4l_fwd_step<8>(sv[8], acc, fin);
-            e4l_fwd_step<9>(sv[9], acc, fin);
-            e4l_fwd_step<10>(sv[10], acc, fin);
-            e4l_fwd_step<11>(sv[11], acc, fin);
-            e4l_fwd_step<12>(sv[12], acc, fin);
-            e4l_fwd_step<13>(sv[13], acc, fin);
-            e4l_fwd_step<14>(sv[14], acc, fin);
-            e4l_fwd_step<15>(sv[15], acc, fin);
+            if (LONG) {
+                e4l_fwd_step_long<0>(sv[0], acc, far, fin);
+                e4l_fwd_step_long<1>(sv[1], acc, far, fin);
+                e4l_fwd_step_long<2>(sv[2], acc, far, fin);
+                e4l_fwd_step_long<3>(sv[3], acc, far, fin);
+                e4l_fwd_step_long<4>(sv[4], acc, far, fin);
+                e4l_fwd_step_long<5>(sv[5], acc, far, fin);
+                e4l_fwd_step_long<6>(sv[6], acc, far, fin);
+                e4l_fwd_step_long<7>(sv[7], acc, far, fin);
+                e4l_fwd_step_long<8>(sv[8], acc, far, fin);
+                e4l_fwd_step_long<9>(sv[9], acc, far, fin);
+                e4l_fwd_step_long<10>(sv[10], acc, far, fin);
+                e4l_fwd_step_long<11>(sv[11], acc, far, fin);
+                e4l_fwd_step_long<12>(sv[12], acc, far, fin);
+                e4l_fwd_step_long<13>(sv[13], acc, far, fin);
+                e4l_fwd_step_long<14>(sv[14], acc, far, fin);
+                e4l_fwd_step_long<15>(sv[15], acc, far, fin);
+                // the long matches of this block: a[start] * w into the position 17..47 ahead of the block's first
+                for (uint32_t e = 0; e < n_ovf; ++e) {
+                    const uint4 ent = *reinterpret_cast<const uint4*>(ovf + 16u + e * 16u);  // same address in every lane
+                    const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.x);
+                    const uint32_t tgt = (src & 15u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.y);  // 17..47
+                    const double contrib = readlane_f64(fin, src) * __hiloint2double((int)ent.w, (int)ent.z);
+                    const bool mine = r == (src >> 4) && l == (tgt & 15u);
+                    if (tgt < 32u)
+                        acc += mine ? contrib : 0.0;
+                    else
+                        far += mine ? contrib : 0.0;
+                }
+            } else {
+                e4l_fwd_step<0>(sv[0], acc, fin);
+                e4l_fwd_step<1>(sv[1], acc, fin);
+                e4l_fwd_step<2>(sv[2], acc, fin);
+                e4l_fwd_step<3>(sv[3], acc, fin);
+                e4l_fwd_step<4>(sv[4], acc, fin);
+                e4l_fwd_step<5>(sv[5], acc, fin);
+                e4l_fwd_step<6>(sv[6], acc, fin);
+                e4l_fwd_step<7>(sv[7], acc, fin);
+                e4l_fwd_step<8>(sv[8], acc, fin);
+                e4l_fwd_step<9>(sv[9], acc, fin);
+                e4l_fwd_step<10>(sv[10], acc, fin);
+                e4l_fwd_step<11>(sv[11], acc, fin);
+                e4l_fwd_step<12>(sv[12], acc, fin);
+                e4l_fwd_step<13>(sv[13], acc, fin);
+                e4l_fwd_step<14>(sv[14], acc, fin);
+                e4l_fwd_step<15>(sv[15], acc, fin);
+            }
             // a[pg] and the block's exponent -> scratch (snippet s: n + 1 values at soffs[s] + s)
             if (live && pg[g] <= n) {
                 P.alpha[beg + s + pg[g]] = fin;
@@ -238,6 +354,7 @@ __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
             const int e = row_max_exponent(acc);
             if (e > -100000) {
                 acc = ldexp(acc, -e);
+                if (LONG) far = ldexp(far, -e);
                 erow += e;
             }
         }
@@ -252,8 +369,10 @@ __global__ __launch_bounds__(1024) void estep4l_fwd_kernel(Estep4Params P) {
     if (zsum != 0.0) atomicAdd(P.logz_sum, zsum);
 }
 
-template <bool DROPOUT, int PPL>
+template <bool DROPOUT, int PPL, bool LONG>
 __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
+    static_assert(!LONG || PPL == 1, "the long-token build runs one position per lane");
+    constexpr uint32_t LMX = LONG ? 32u : 16u;  // longest token
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = 16;
     constexpr uint32_t SPAN = 16u * PPL;
@@ -265,6 +384,8 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
     const uint32_t n_hot = P.n_hot;  // slots summed in LDS (wave-uniform); entry n_hot is {0, 0}: "no token"
     unsigned char* wbase = smem + (n_hot + 1u) * 16u + (size_t)wave * (PPL * kE4LEntries * 4u);
     uint32_t* hl = reinterpret_cast<uint32_t*>(wbase);  // PPL groups of slots
+    // LONG: this wave's overflow list, behind the match buffers of the block's waves
+    unsigned char* ovf = smem + (n_hot + 1u) * 16u + (size_t)(blockDim.x >> 6) * (PPL * kE4LEntries * 4u) + (size_t)wave * kE4LOvfBytes;
     // expected counts go to one of n_replicas copies of the slot array (reduced afterwards):
     // a handful of very frequent tokens would otherwise serialise every wave's atomics
     double* __restrict__ expected_slot = P.expected_slot + (size_t)(blockIdx.x % P.n_replicas) * P.n_slots_rev;
@@ -276,7 +397,7 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
     uint32_t s = 0, n = 0, y0 = 0, smp = 0;
     uint64_t beg = 0, sbase = 0, ebase = 0;
     bool live = false, need_new = true;
-    double acc = 0.0, inv_an = 0.0;
+    double acc = 0.0, far = 0.0, inv_an = 0.0;
     double cfw[PPL + 1];  // a[p] / a[n] of this lane's start positions y0 + 16 g + l, g = 0 .. PPL
     int efw[PPL + 1];     // Ea(p) - Ea(n)
     int eb = 0, ean = 0;
@@ -316,6 +437,7 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
             }
             y0 = 0;
             acc = (l == 0u) ? 1.0 : 0.0;  // EOS: beta = 0 in the log domain
+            far = 0.0;
             eb = 0;
 #pragma unroll
             for (int g = 0; g <= PPL; ++g) load_fwd(16u * g + l, cfw[g], efw[g]);
@@ -334,7 +456,7 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
         for (int g = 0; g < PPL; ++g) {
             yq[g] = y0 + 16u * g + l;
             qq[g] = (live && yq[g] < n) ? (n - yq[g]) : 0u;  // bytes available before q
-            maxd[g] = qq[g] < LM ? qq[g] : LM;
+            maxd[g] = qq[g] < LMX ? qq[g] : LMX;
             cur[g] = 0;
             base[g] = P.root_rev;
             alive[g] = maxd[g] > 0;
@@ -394,6 +516,45 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
                 }
             }
         }
+        uint32_t n_ovf = 0;  // wave-uniform: overflow entries of this block
+        if (LONG) {
+            bool more = alive[0] && maxd[0] > 16u;
+            if (__builtin_amdgcn_ballot_w64(more) != 0) {
+                // text[q - 32 .. q - 16): the 16 bytes below the window (front pad of 256 bytes: `low` >= -240)
+                const uint32_t* __restrict__ wl = wp - 4;
+                uint32_t b2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b2[j] = __builtin_amdgcn_alignbyte(wl[j + 1], wl[j], sh);
+                for (uint32_t d = 16; d < 32u; ++d) {
+                    more = more && d < maxd[0];
+                    if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+                    const uint32_t bi = 31u - d;  // text[q - 1 - d] is byte 31 - d of [q - 32, q)
+                    const uint32_t word = (bi & 8u) ? ((bi & 4u) ? b2[3] : b2[2]) : ((bi & 4u) ? b2[1] : b2[0]);
+                    const uint32_t c = (word >> ((bi & 3u) * 8u)) & 0xFFu;
+                    const uint32_t t = more ? (base[0] ^ c) : 0u;
+                    const uint4 rec = load_rec(trie, t);
+                    more = more && rec.x == cur[0];
+                    bool term = more && (rec.y >> 31) != 0u;
+                    if (more) {
+                        cur[0] = t;
+                        base[0] = rec.y & 0x7FFFFFFFu;
+                    }
+                    if (DROPOUT) {
+                        if (term) term = !(dropout_u01(P.seed, smp, sbase + (uint64_t)(qq[0] - d - 1u), d + 1u) < P.dropout);
+                    }
+                    const uint64_t tm = __builtin_amdgcn_ballot_w64(term);
+                    if (tm != 0) {  // wave-uniform
+                        const uint32_t e = n_ovf + __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u));
+                        n_ovf += (uint32_t)__builtin_popcountll(tm);
+                        if (term && e < kE4LOvfCap) *reinterpret_cast<uint4*>(ovf + 16u + e * 16u) = make_uint4(lane | ((d + 1u) << 8), t, rec.z, rec.w);
+                    }
+                }
+                if (n_ovf > kE4LOvfCap) {  // the pass goes to the generic kernel
+                    atomicMax(P.range_flag, 2ULL);
+                    n_ovf = kE4LOvfCap;
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
 
         // ---- backward recursion + marginals: 16 static steps per group, then the row is rescaled
@@ -412,25 +573,70 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
                 // ... or, for a slot outside the hot set, the trie record in HBM
                 if (hvs[u] != kNoSlot && hvs[u] >= n_hot) sv[u] = reinterpret_cast<const double*>(P.trie_rev)[2u * hvs[u] + 1u];
             }
-            e4l_bwd_step<0>(sv[0], hvs[0], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<1>(sv[1], hvs[1], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<2>(sv[2], hvs[2], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<3>(sv[3], hvs[3], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<4>(sv[4], hvs[4], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<5>(sv[5], hvs[5], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<6>(sv[6], hvs[6], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<7>(sv[7], hvs[7], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<8>(sv[8], hvs[8], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<9>(sv[9], hvs[9], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<10>(sv[10], hvs[10], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<11>(sv[11], hvs[11], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<12>(sv[12], hvs[12], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<13>(sv[13], hvs[13], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<14>(sv[14], hvs[14], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-            e4l_bwd_step<15>(sv[15], hvs[15], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            if (LONG) {
+                double fin = 0.0;
+                e4l_bwd_step_long<0>(sv[0], hvs[0], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<1>(sv[1], hvs[1], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<2>(sv[2], hvs[2], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<3>(sv[3], hvs[3], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<4>(sv[4], hvs[4], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<5>(sv[5], hvs[5], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<6>(sv[6], hvs[6], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<7>(sv[7], hvs[7], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<8>(sv[8], hvs[8], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<9>(sv[9], hvs[9], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<10>(sv[10], hvs[10], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<11>(sv[11], hvs[11], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<12>(sv[12], hvs[12], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<13>(sv[13], hvs[13], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<14>(sv[14], hvs[14], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                e4l_bwd_step_long<15>(sv[15], hvs[15], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc, far, fin);
+                // the long matches of this block: b[q] * w into the position 17..47 further from the end, and their
+                // marginals (the lane that owns the match's end position has everything of its snippet at hand)
+                for (uint32_t e = 0; e < n_ovf; ++e) {
+                    const uint4 ent = *reinterpret_cast<const uint4*>(ovf + 16u + e * 16u);  // same address in every lane
+                    const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ent.x & 0xFFu));
+                    const uint32_t tgt = (src & 15u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(ent.x >> 8));  // 17..47
+                    const double w = __hiloint2double((int)ent.w, (int)ent.z);
+                    const double contrib = readlane_f64(fin, src) * w;
+                    if (lane == src) {  // lattice.rs:305-307 for this match: its start lies tgt positions before the block's last
+                        const uint32_t pp = n - (y0 + tgt);
+                        const double cp = P.alpha[beg + s + pp] * inv_an;
+                        const int ep = P.alpha_exp[ebase + (pp >> 4)] - ean;
+                        const double mg = ldexp(fin * w * cp, ep + eb);
+                        if (ent.y < n_hot)
+                            atomicAdd(&hot[ent.y].x, mg);
+                        else if (cold_ok)
+                            atomicAdd(&expected_slot[ent.y], mg);
+                    }
+                    const bool mine = r == (src >> 4) && l == (tgt & 15u);
+                    if (tgt < 32u)
+                        acc += mine ? contrib : 0.0;
+                    else
+                        far += mine ? contrib : 0.0;
+                }
+            } else {
+                e4l_bwd_step<0>(sv[0], hvs[0], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<1>(sv[1], hvs[1], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<2>(sv[2], hvs[2], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<3>(sv[3], hvs[3], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<4>(sv[4], hvs[4], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<5>(sv[5], hvs[5], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<6>(sv[6], hvs[6], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<7>(sv[7], hvs[7], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<8>(sv[8], hvs[8], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<9>(sv[9], hvs[9], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<10>(sv[10], hvs[10], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<11>(sv[11], hvs[11], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<12>(sv[12], hvs[12], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<13>(sv[13], hvs[13], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<14>(sv[14], hvs[14], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<15>(sv[15], hvs[15], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+            }
             const int e = row_max_exponent(acc);
             if (e > -100000) {
                 acc = ldexp(acc, -e);
+                if (LONG) far = ldexp(far, -e);
                 eb += e;
             }
         }
@@ -457,41 +663,47 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
 }
 
 typedef void (*estep4l_fn)(Estep4Params);
-static estep4l_fn pick_fwd(bool dropout, int ppl) {
-    if (ppl == 4) return dropout ? estep4l_fwd_kernel<true, 4> : estep4l_fwd_kernel<false, 4>;
-    if (ppl == 2) return dropout ? estep4l_fwd_kernel<true, 2> : estep4l_fwd_kernel<false, 2>;
-    return dropout ? estep4l_fwd_kernel<true, 1> : estep4l_fwd_kernel<false, 1>;
+static estep4l_fn pick_fwd(bool dropout, int ppl, bool long_tokens) {
+    if (long_tokens) return dropout ? estep4l_fwd_kernel<true, 1, true> : estep4l_fwd_kernel<false, 1, true>;
+    if (ppl == 4) return dropout ? estep4l_fwd_kernel<true, 4, false> : estep4l_fwd_kernel<false, 4, false>;
+    if (ppl == 2) return dropout ? estep4l_fwd_kernel<true, 2, false> : estep4l_fwd_kernel<false, 2, false>;
+    return dropout ? estep4l_fwd_kernel<true, 1, false> : estep4l_fwd_kernel<false, 1, false>;
 }
-static estep4l_fn pick_bwd(bool dropout, int ppl) {
-    if (ppl == 4) return dropout ? estep4l_bwd_kernel<true, 4> : estep4l_bwd_kernel<false, 4>;
-    if (ppl == 2) return dropout ? estep4l_bwd_kernel<true, 2> : estep4l_bwd_kernel<false, 2>;
-    return dropout ? estep4l_bwd_kernel<true, 1> : estep4l_bwd_kernel<false, 1>;
+static estep4l_fn pick_bwd(bool dropout, int ppl, bool long_tokens) {
+    if (long_tokens) return dropout ? estep4l_bwd_kernel<true, 1, true> : estep4l_bwd_kernel<false, 1, true>;
+    if (ppl == 4) return dropout ? estep4l_bwd_kernel<true, 4, false> : estep4l_bwd_kernel<false, 4, false>;
+    if (ppl == 2) return dropout ? estep4l_bwd_kernel<true, 2, false> : estep4l_bwd_kernel<false, 2, false>;
+    return dropout ? estep4l_bwd_kernel<true, 1, false> : estep4l_bwd_kernel<false, 1, false>;
 }
 
 hipError_t estep4l_prepare() {
     for (int d = 0; d < 2; d++)
-        for (int ppl = 1; ppl <= 4; ppl *= 2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_fwd(d == 1, ppl)),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_bwd(d == 1, ppl)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
+        for (int ppl = 1; ppl <= 4; ppl *= 2)
+            for (int lg = 0; lg < (ppl == 1 ? 2 : 1); lg++) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_fwd(d == 1, ppl, lg == 1)),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(pick_bwd(d == 1, ppl, lg == 1)),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+            }
     return hipSuccess;
 }
 
 // forward: 8 KiB * ppl of LDS per wave: 5 blocks x 4 waves / 2 x 5 / 1 x 5 per CU for ppl = 1 / 2 / 4
-hipError_t launch_estep4l_fwd(const Estep4Params& p, int ppl, uint32_t num_cus, hipStream_t stream) {
-    const uint32_t waves = ppl == 1 ? 4u : 5u, bpc = ppl == 1 ? 5u : (ppl == 2 ? 2u : 1u);
+// (long_tokens: vocabularies with tokens of 17..32 bytes — one position per lane, an overflow list per wave)
+hipError_t launch_estep4l_fwd(const Estep4Params& p, int ppl, bool long_tokens, uint32_t num_cus, hipStream_t stream) {
+    if (long_tokens) ppl = 1;
+    const uint32_t waves = ppl == 1 ? 4u : 5u, bpc = ppl == 1 ? (long_tokens ? 4u : 5u) : (ppl == 2 ? 2u : 1u);
     const uint64_t want = (p.n_snips + 4 * waves - 1) / (4 * waves);
     const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus * bpc ? (want ? want : 1) : (uint64_t)num_cus * bpc);
-    hipLaunchKernelGGL(pick_fwd(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * waves), waves * (uint32_t)ppl * kE4LEntries * 8u,
-                       stream, p);
+    const uint32_t lds = waves * (uint32_t)ppl * kE4LEntries * 8u + (long_tokens ? waves * kE4LOvfBytes : 0u);
+    hipLaunchKernelGGL(pick_fwd(p.dropout > 0.0, ppl, long_tokens), dim3(blocks), dim3(64u * waves), lds, stream, p);
     return hipGetLastError();
 }
 // backward: ONE block per CU: 16 / 8 / 4 waves x 4 KiB * ppl of match buffers (slots), the rest of the 160 KiB hot entries
-hipError_t launch_estep4l_bwd(const Estep4Params& p0, int ppl, uint32_t num_cus, hipStream_t stream) {
+hipError_t launch_estep4l_bwd(const Estep4Params& p0, int ppl, bool long_tokens, uint32_t num_cus, hipStream_t stream) {
+    if (long_tokens) ppl = 1;
     // groups of 16 positions per block: 16 (x 4 KiB of match buffer) leave 96 KiB = 6 143 hot entries of 16
     // bytes; fewer groups, more slots summed in LDS instead of by memory-side atomics but fewer waves to hide
     // the gathers: 44.3 / 40.9 / 39.5 ms per GiB with 12 / 14 / 16 groups, 51.0 ms with the 12 groups and
@@ -503,11 +715,12 @@ hipError_t launch_estep4l_bwd(const Estep4Params& p0, int ppl, uint32_t num_cus,
     }
     Estep4Params p = p0;
     const uint32_t waves = std::max(1u, groups / (uint32_t)ppl);
-    p.n_hot = (160u * 1024u - waves * (uint32_t)ppl * kE4LEntries * 4u) / 16u - 1u;
+    const uint32_t wave_bytes = (uint32_t)ppl * kE4LEntries * 4u + (long_tokens ? kE4LOvfBytes : 0u);
+    p.n_hot = (160u * 1024u - waves * wave_bytes) / 16u - 1u;
     const uint64_t want = (p.n_snips + 4 * waves - 1) / (4 * waves);
     const uint32_t blocks = (uint32_t)(want < (uint64_t)num_cus ? (want ? want : 1) : (uint64_t)num_cus);
-    const uint32_t lds = (p.n_hot + 1u) * 16u + waves * (uint32_t)ppl * kE4LEntries * 4u;
-    hipLaunchKernelGGL(pick_bwd(p.dropout > 0.0, ppl), dim3(blocks), dim3(64u * waves), lds, stream, p);
+    const uint32_t lds = (p.n_hot + 1u) * 16u + waves * wave_bytes;
+    hipLaunchKernelGGL(pick_bwd(p.dropout > 0.0, ppl, long_tokens), dim3(blocks), dim3(64u * waves), lds, stream, p);
     return hipGetLastError();
 }
 

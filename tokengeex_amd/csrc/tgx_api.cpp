@@ -1818,7 +1818,7 @@ static tgx_status ensure_reverse_trie(tgx_model* m) {
     // Linear-domain E-step (estep4l.hip): its tables carry w = exp(score).  Whether a pass can use it
     // (every position has an incoming token, values stay inside the f64 range) is decided per pass by
     // the forward kernel itself; scores beyond +-300 would overflow exp() or underflow within a block.
-    bool ok = m->lm <= 16 && m->scores_finite;
+    bool ok = m->lm <= 32 && m->scores_finite;  // (17..32 bytes: the long-token builds, one position per lane)
     for (uint32_t i = 0; ok && i < V; i++) ok = m->vocab_scores[i] >= -300.0 && m->vocab_scores[i] <= 300.0;
     if (ok) {
         auto upload_weights = [&](const tgx::FlatTrie& ft, void** dst) -> hipError_t {
@@ -1845,8 +1845,13 @@ static tgx_status ensure_reverse_trie(tgx_model* m) {
 
 // E-step on the four-snippets-per-wave kernels (estep4.hip).  Caller holds m->mu and has
 // built the reversed trie.
+// `fallback` (vocabularies with tokens of 17..32 bytes only): set when the linear-domain kernels cannot do the
+// pass (a position without an incoming token, the f64 range left, an overflow list full) — there are no log-domain
+// rows4 kernels for such vocabularies, the caller goes on to the generic kernel; `expected` is untouched then.
 static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout,
-                              uint64_t seed, double* expected, double* logz_sum) {
+                              uint64_t seed, double* expected, double* logz_sum, bool* fallback) {
+    const bool long_tokens = m->lm > 16;
+    if (fallback) *fallback = false;
     const uint64_t S = c->n_samples, N = c->n_bytes;
     // the work list: every sample cut at multiples of snippet_len (src/prune.rs:83)
     std::vector<uint64_t> soffs;
@@ -1979,7 +1984,7 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "E-step queue reset failed"));
         time_begin(m, use_linear ? "estep4l_fwd_kernel" : "estep4_fwd_kernel");
-        if ((use_linear ? tgx::launch_estep4l_fwd(p, eppl_fwd, (uint32_t)m->num_cus, m->stream)
+        if ((use_linear ? tgx::launch_estep4l_fwd(p, eppl_fwd, long_tokens, (uint32_t)m->num_cus, m->stream)
                         : tgx::launch_estep4_fwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "estep4 forward launch failed"));
         time_end(m);
@@ -1989,12 +1994,16 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
                 hipStreamSynchronize(m->stream) != hipSuccess)
                 return cleanup(fail(TGX_ERR_DEVICE, "E-step forward pass failed: %s", hipGetErrorString(hipGetLastError())));
             if (flag != 0) {
+                if (long_tokens) {
+                    if (fallback) *fallback = true;
+                    return cleanup(TGX_OK);
+                }
                 use_linear = false;
                 continue;
             }
         }
         time_begin(m, use_linear ? "estep4l_bwd_kernel" : "estep4_bwd_kernel");
-        if ((use_linear ? tgx::launch_estep4l_bwd(p, eppl_bwd, (uint32_t)m->num_cus, m->stream)
+        if ((use_linear ? tgx::launch_estep4l_bwd(p, eppl_bwd, long_tokens, (uint32_t)m->num_cus, m->stream)
                         : tgx::launch_estep4_bwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "estep4 backward launch failed"));
         time_end(m);
@@ -2044,8 +2053,16 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
     const uint64_t S = c->n_samples, N = c->n_bytes;
     {
         const char* force = getenv("TGX_PATH");
-        if (m->lm <= 16 && m->scores_finite && !(force && strcmp(force, "fused") == 0))
-            return estep_rows4(m, c, snippet_len, dropout, seed, expected, logz_sum);
+        const bool rows = m->scores_finite && !(force && strcmp(force, "fused") == 0);
+        if (rows && m->lm <= 16) return estep_rows4(m, c, snippet_len, dropout, seed, expected, logz_sum, nullptr);
+        // tokens of 17..32 bytes (after `merge`): the linear-domain kernels' long-token builds; the generic kernel
+        // below where they cannot do the pass
+        const char* force_log = getenv("TGX_ESTEP");
+        if (rows && m->lm <= 32 && m->estep_linear_ok && !(force_log && strcmp(force_log, "log") == 0)) {
+            bool fallback = false;
+            st = estep_rows4(m, c, snippet_len, dropout, seed, expected, logz_sum, &fallback);
+            if (st != TGX_OK || !fallback) return st;
+        }
     }
     const size_t n_rev = m->flat_rev.table.size();
     uint32_t n_rep = 256;
