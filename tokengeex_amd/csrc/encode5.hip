@@ -6,17 +6,20 @@
 //
 //   * 8-byte label-checked trie records (trie_build.h: Trie8Rec).  A walk keeps only `base`; a step is one
 //     8-byte gather {label | terminal | next base, score reference} (0.9 cycles per lane, measured:
-//     profiles/r02/a_gather2.txt) and one compare of the label with the text byte.
+//     profiles/r02/a_gather_8byte_records.txt) and one compare of the label with the text byte.
 //   * scores are not carried through the match buffer.  The distinct score VALUES of the vocabulary (a few
 //     thousand for generate-style vocabularies, which score tokens by integer counts) sit in a table in
 //     the block's LDS, ordered by how often their tokens are expected to match; the match buffer holds 2-byte
 //     LDS addresses of table entries ("no token" = the address of a -inf entry), 2 KiB per wave and 64
-//     positions instead of 8 KiB.  A token whose value did not make the table ("cold") gets an entry of a
-//     small per-wave pool, filled from HBM while the walk goes on; a wave whose pool runs out marks the samples
-//     it is working on, and the host redoes exactly those with encode4_kernel.
+//     positions instead of 8 KiB.  A token whose value did not make the table ("cold": COLD builds) gets an
+//     entry of a per-wave pool — the walk leaves the trie slot there and one batch of loads after the walk
+//     replaces the slots by the scores; a wave whose pool runs out marks the samples it is working on, and the
+//     host redoes exactly those with encode4_kernel.  (Models with cold values run encode4_kernel by default:
+//     tgx_api.cpp; the COLD builds serve encode6_kernel's long samples and TGX_PATH=rows5.)
+//   * the PPL walks of a lane are staggered (Walk5), and the relaxation runs on relax5_step (device_common.h).
 //
-// The relaxation is encode4_kernel's (relax4_step: same candidate order, strict '>', forced restart), so the
-// back-pointer bytes and the per-sample status are bit-identical and trace_kernel is shared.
+// Same candidate order and strict '>' as encode4_kernel, so the back-pointer bytes and the per-sample status
+// are bit-identical and trace_kernel is shared.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
