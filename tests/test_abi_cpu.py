@@ -42,6 +42,19 @@ def test_fails_loudly_without_gpu():
         VocabularyGenerator(8, 1.0).feed(["abc abc"])
 
 
+def test_packed_vocabulary_container():
+    """_lib.Packed: the prune driver's vocabulary between passes — subsets without a Python loop."""
+    rng = np.random.default_rng(3)
+    items = [bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) for n in rng.integers(0, 20, 500)]
+    p = _lib.Packed.of(items)
+    assert len(p) == 500 and p.tolist() == items and _lib.Packed.of(p) is p
+    idx = rng.integers(0, 500, 300)
+    assert p.take(idx).tolist() == [items[int(i)] for i in idx]
+    assert p.take([]).tolist() == [] and _lib.Packed.of([]).tolist() == []
+    flat, offs = _lib.pack(p.take(idx))
+    assert flat.dtype == np.uint8 and offs.dtype == np.uint64 and int(offs[-1]) == flat.size
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "tokengeex_amd")
     for dirpath, _, files in os.walk(pkg):
