@@ -389,7 +389,7 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
     // expected counts go to one of n_replicas copies of the slot array (reduced afterwards):
     // a handful of very frequent tokens would otherwise serialise every wave's atomics
     double* __restrict__ expected_slot = P.expected_slot + (size_t)(blockIdx.x % P.n_replicas) * P.n_slots_rev;
-    const bool cold_ok = (P.flags & 8u) == 0u;
+    constexpr bool cold_ok = true;  // (a run-time switch here — TGX_FLAGS=8, the experiment of y_estep_bwd_without_cold_atomics.txt — cost four instructions per step: a spilled scalar flag)
     for (uint32_t i = threadIdx.x; i <= n_hot; i += blockDim.x)
         hot[i] = make_double2(0.0, (i < n_hot && i < P.n_slots_rev) ? reinterpret_cast<const double*>(P.trie_rev)[2u * i + 1u] : 0.0);
     __syncthreads();

@@ -22,6 +22,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     print("   ", {k: round(v, 3) for k, v in best[1].items()}, flush=True)
     sys.exit(0)
 size = sys.argv[1] if len(sys.argv) > 1 else "1024"
-for cfg in ({}, {"TGX_DEBUG": "1", "TGX_FLAGS": "8"}, {"TGX_BWD_GROUPS": "14"}, {"TGX_BWD_GROUPS": "12"}):
+for cfg in ({}, {"TGX_BWD_GROUPS": "14"}, {"TGX_BWD_GROUPS": "12"}):
     print(cfg, flush=True)
     subprocess.run([sys.executable, os.path.abspath(__file__), "--one", size], env=dict(os.environ, **cfg), timeout=300)
