@@ -254,6 +254,8 @@ tgx_status tgx_prune_m_step(const double *expected, const uint8_t *keep, uint32_
 tgx_status tgx_prune_alternatives(const tgx_flat_trie *trie, const uint8_t *bytes, const uint64_t *offs,
                                   const double *scores, uint32_t vocab_size, uint8_t *always_keep,
                                   uint32_t *alt_offs, uint32_t **alt_ids);
+/* The same for the vocabulary of a model, over the model's own table (no second trie is built). */
+tgx_status tgx_model_prune_alternatives(const tgx_model *m, uint8_t *always_keep, uint32_t *alt_offs, uint32_t **alt_ids);
 /* prune_vocab, second half — src/prune.rs:246-318: ids of the pruned vocabulary in its final
  * order (score descending).  out_idx needs room for V entries. */
 tgx_status tgx_prune_select(const uint64_t *freq, const uint8_t *keep, const uint8_t *always_keep,

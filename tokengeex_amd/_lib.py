@@ -79,6 +79,7 @@ SYMBOLS = {
     "tgx_digamma": (_d, [_d]),
     "tgx_prune_m_step": (_i, [_vp, _vp, _u32, _vp, _vp, C.POINTER(C.c_uint32)]),
     "tgx_prune_alternatives": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _pvp]),
+    "tgx_model_prune_alternatives": (_i, [_vp, _vp, _vp, _pvp]),
     "tgx_prune_select": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u64, _u32, _vp, C.POINTER(C.c_uint32)]),
     "tgx_last_kernel_times": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), _i]),
     "tgx_last_algorithmic_bytes": (_u64, [_vp]),
@@ -434,6 +435,19 @@ class NativeModel:
         check(lib.tgx_encode_batch_host(self._h, ptr(flat) if flat.size else None, ptr(offs), n, float(dropout),
                                         seed & (2**64 - 1), ptr(ids_out), ids_out.size, ptr(out_offs), C.byref(t)))
         return ids_out[: t.value], out_offs
+
+    def prune_alternatives(self) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """FlatTrie.prune_alternatives for this model's vocabulary, over the model's own table
+        -> (always_keep u8[V], alt_offs u32[V+1], alt_ids u32[...]) — src/prune.rs:179-203."""
+        V = self.vocab_size
+        always_keep = np.zeros(V, np.uint8)
+        alt_offs = np.zeros(V + 1, np.uint32)
+        p = C.c_void_p()
+        check(lib.tgx_model_prune_alternatives(self._h, ptr(always_keep), ptr(alt_offs), C.byref(p)))
+        k = int(alt_offs[V])
+        ids = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(k, 1),))[:k].copy()
+        lib.tgx_free(p)
+        return always_keep, alt_offs, ids
 
     def encode_corpus(self, corpus: NativeCorpus, dropout: float = 0.0, seed: int = 0) -> NativeResult:
         h = C.c_void_p()

@@ -226,7 +226,15 @@ tgx_status tgx_prune_m_step(const double* expected, const uint8_t* keep, uint32_
 tgx_status tgx_prune_alternatives(const tgx_flat_trie* trie, const uint8_t* bytes, const uint64_t* offs,
                                   const double* scores, uint32_t vocab_size, uint8_t* always_keep,
                                   uint32_t* alt_offs, uint32_t** alt_ids) {
-    if (!trie || !offs || !scores || !always_keep || !alt_offs || !alt_ids) return perr(TGX_ERR_INVALID, "tgx_prune_alternatives: NULL argument");
+    if (!trie) return perr(TGX_ERR_INVALID, "tgx_prune_alternatives: NULL argument");
+    return (tgx_status)tgx_prune_alternatives_flat(&trie->flat, bytes, offs, scores, vocab_size, always_keep, alt_offs, alt_ids);
+}
+
+// the same over a table that already exists (tgx_model_prune_alternatives, tgx_api.cpp: the model's own trie)
+int tgx_prune_alternatives_flat(const tgx::FlatTrie* flat_trie, const uint8_t* bytes, const uint64_t* offs,
+                                       const double* scores, uint32_t vocab_size, uint8_t* always_keep,
+                                       uint32_t* alt_offs, uint32_t** alt_ids) {
+    if (!flat_trie || !offs || !scores || !always_keep || !alt_offs || !alt_ids) return perr(TGX_ERR_INVALID, "tgx_prune_alternatives: NULL argument");
     // The reference walks the vocabulary serially; the tokens are independent (each gets its own lattice), so
     // contiguous id ranges go to host threads and the per-range lists are concatenated in id order: the
     // result does not depend on the number of threads.  (1.0 s at 500 000 tokens on one core.)
@@ -244,7 +252,7 @@ tgx_status tgx_prune_alternatives(const tgx_flat_trie* trie, const uint8_t* byte
             alt_offs[id] = (uint32_t)flat_alts.size();  // relative to the range; rebased below
             always_keep[id] = 1;
             const uint32_t n = (uint32_t)(offs[id + 1] - offs[id]);
-            build_lattice(trie->flat, scores, bytes + offs[id], n, &L);
+            build_lattice(*flat_trie, scores, bytes + offs[id], n, &L);
             nbest2(&L, &paths);
             if (paths.size() > 1 && paths[0].size() > 1) always_keep[id] = 0;
             if (paths.size() > 1 && paths[0].size() == 1)

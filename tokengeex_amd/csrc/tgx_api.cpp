@@ -1004,6 +1004,14 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
     return TGX_OK;
 }
 
+// tgx_prune_alternatives over the model's own double-array (the prune driver has a model of the same vocabulary
+// at hand: no second table is built)
+tgx_status tgx_model_prune_alternatives(const tgx_model* m, uint8_t* always_keep, uint32_t* alt_offs, uint32_t** alt_ids) {
+    if (!m) return fail(TGX_ERR_INVALID, "tgx_model_prune_alternatives: NULL argument");
+    return (tgx_status)tgx_prune_alternatives_flat(&m->flat, m->vocab_bytes.data(), m->vocab_offs.data(), m->vocab_scores.data(),
+                                                   m->vocab_size, always_keep, alt_offs, alt_ids);
+}
+
 void tgx_model_destroy(tgx_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);

@@ -137,6 +137,13 @@ uint64_t flat_common_prefix_search(const FlatTrie& t, const uint8_t* s, uint64_t
 
 }  // namespace tgx
 
+// prune_host.cpp: tgx_prune_alternatives over a table that already exists (a handle's, or a model's own)
+// prune_host.cpp: tgx_prune_alternatives over a table that already exists (a handle's, or a model's own);
+// returns a tgx_status
+extern "C" int tgx_prune_alternatives_flat(const tgx::FlatTrie* flat_trie, const uint8_t* bytes, const uint64_t* offs,
+                                const double* scores, uint32_t vocab_size, uint8_t* always_keep,
+                                uint32_t* alt_offs, uint32_t** alt_ids);
+
 // host-only handle of include/tgx.h's tgx_flat_trie_* functions (tgx_api.cpp, prune_host.cpp)
 struct tgx_flat_trie {
     tgx::FlatTrie flat;

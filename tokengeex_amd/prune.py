@@ -74,8 +74,7 @@ class ModelVocabularyPruner:
         toks, scores, keep = arrays
         V = len(toks)
         pruned_size = max(int(V * self.shrink_factor), self.vocab_size)
-        trie = _lib.FlatTrie(toks, scores)
-        always_keep, alt_offs, alt_ids = trie.prune_alternatives(toks, scores)
+        always_keep, alt_offs, alt_ids = model.prune_alternatives()  # over the model's own table
         freq = tdist.allreduce_vector(model.count_tokens(corpus), self.dist, self.reduce_device)
         n_samples = tdist.allreduce_scalar(corpus.num_samples, self.dist, self.reduce_device)
         out = np.asarray(_lib.prune_select(freq, keep, always_keep, alt_offs, alt_ids, scores, n_samples, pruned_size), np.int64)
