@@ -53,7 +53,7 @@ __device__ __forceinline__ void relax4l_step(double sv, double& acc, uint32_t& b
     far = sel_f64(MU, ninf, far);            // `far` of lane U now stands for position p0 + U + 32
     const double cand = best + sv;           // model.rs:98
     const uint64_t take = __builtin_amdgcn_fcmp(cand, cur, 2 /* OGT: model.rs:101; far wins ties */);
-    acc = sel_f64(take, cand, cur);
+    asm("v_max_f64 %0, %1, %2" : "=v"(acc) : "v"(cur), "v"(cand));  // = take ? cand : cur (finite or -inf values), off the compare (relax5_step)
     bpv = sel_imm_u32<U>(take, curbp);
 }
 
