@@ -234,6 +234,17 @@ struct tgx_corpus {
     uint32_t* d_status = nullptr;
     void* d_scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
+    // E-step work list of the corpus (every sample cut at multiples of snippet_len, longest snippet first) and its
+    // device copies: built on the first pass with a given snippet length, reused by the following ones (prune
+    // runs two E-steps per iteration over the same corpus; building and sorting the list took 5 of 65 ms at 1 GiB)
+    struct EstepWork {
+        uint64_t snippet_len = 0;
+        std::vector<uint64_t> soffs, sbase;
+        std::vector<uint32_t> ssample, order;
+        uint64_t *d_soffs = nullptr, *d_sbase = nullptr;
+        uint32_t *d_order = nullptr, *d_ssample = nullptr;
+        size_t obytes = 0, ordbytes = 0;
+    } es;
     // the scratch above belongs to the corpus, so a pass holds this lock too (always after its model's):
     // two models may work on one resident corpus from two host threads (prune and merge do, src/prune.rs:48)
     std::mutex mu;
@@ -1246,6 +1257,10 @@ void tgx_corpus_free(tgx_corpus* c) {
     pool_free(c->device, c->d_counts, (size_t)c->n_samples * 4 + 256);
     pool_free(c->device, c->d_status, (size_t)c->n_samples * 4 + 256);
     pool_free(c->device, c->d_scan_tmp, c->scan_tmp_bytes);
+    pool_free(c->device, c->es.d_soffs, c->es.obytes);
+    pool_free(c->device, c->es.d_sbase, c->es.obytes);
+    pool_free(c->device, c->es.d_order, c->es.ordbytes);
+    pool_free(c->device, c->es.d_ssample, c->es.ordbytes);
     delete c;
 }
 
@@ -1861,42 +1876,72 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     const bool long_tokens = m->lm > 16;
     if (fallback) *fallback = false;
     const uint64_t S = c->n_samples, N = c->n_bytes;
-    // the work list: every sample cut at multiples of snippet_len (src/prune.rs:83)
-    std::vector<uint64_t> soffs;
-    std::vector<uint32_t> ssample;
-    std::vector<uint64_t> sbase;
-    soffs.reserve(S + N / snippet_len + 2);
-    for (uint64_t i = 0; i < S; i++) {
-        const uint64_t b = c->h_offs[i], e = c->h_offs[i + 1];
-        for (uint64_t o = b; o < e; o += snippet_len) {
-            soffs.push_back(o);
-            ssample.push_back((uint32_t)i);
-            sbase.push_back(o - b);
+    // the work list: every sample cut at multiples of snippet_len (src/prune.rs:83), kept with the corpus
+    tgx_corpus::EstepWork& es = c->es;
+    if (es.snippet_len != snippet_len) {
+        pool_free(c->device, es.d_soffs, es.obytes);
+        pool_free(c->device, es.d_sbase, es.obytes);
+        pool_free(c->device, es.d_order, es.ordbytes);
+        pool_free(c->device, es.d_ssample, es.ordbytes);
+        es.d_soffs = es.d_sbase = nullptr;
+        es.d_order = es.d_ssample = nullptr;
+        es.snippet_len = 0;
+        es.soffs.clear();
+        es.ssample.clear();
+        es.sbase.clear();
+        es.soffs.reserve(S + N / snippet_len + 2);
+        for (uint64_t i = 0; i < S; i++) {
+            const uint64_t b = c->h_offs[i], e = c->h_offs[i + 1];
+            for (uint64_t o = b; o < e; o += snippet_len) {
+                es.soffs.push_back(o);
+                es.ssample.push_back((uint32_t)i);
+                es.sbase.push_back(o - b);
+            }
         }
+        const uint64_t K0 = es.soffs.size();
+        es.soffs.push_back(N);
+        // a snippet's end is the next snippet's start except across empty samples: offsets stay exact
+        // because snippets tile [0, N) in order
+        es.order.resize(K0);
+        std::iota(es.order.begin(), es.order.end(), 0u);
+        const std::vector<uint64_t>& so = es.soffs;
+        std::stable_sort(es.order.begin(), es.order.end(), [&so](uint32_t a, uint32_t b) {
+            return so[a + 1] - so[a] > so[b + 1] - so[b];
+        });
+        es.obytes = (size_t)(K0 + 1) * 8 + 256;
+        es.ordbytes = (size_t)K0 * 4 + 256;
+        if (pool_alloc(c->device, es.obytes, (void**)&es.d_soffs) != hipSuccess ||
+            pool_alloc(c->device, es.obytes, (void**)&es.d_sbase) != hipSuccess ||
+            pool_alloc(c->device, es.ordbytes, (void**)&es.d_order) != hipSuccess ||
+            pool_alloc(c->device, es.ordbytes, (void**)&es.d_ssample) != hipSuccess)
+            return fail(TGX_ERR_DEVICE, "out of device memory (E-step work list)");
+        if (hipMemcpyAsync(es.d_soffs, es.soffs.data(), (K0 + 1) * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+            (K0 && hipMemcpyAsync(es.d_sbase, es.sbase.data(), K0 * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
+            (K0 && hipMemcpyAsync(es.d_order, es.order.data(), K0 * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
+            (K0 && hipMemcpyAsync(es.d_ssample, es.ssample.data(), K0 * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
+            hipStreamSynchronize(m->stream) != hipSuccess)
+            return fail(TGX_ERR_DEVICE, "E-step work list upload failed");
+        es.snippet_len = snippet_len;
     }
-    const uint64_t K = soffs.size();
-    soffs.push_back(N);
-    // a snippet's end is the next snippet's start except across empty samples: offsets stay exact
-    // because snippets tile [0, N) in order
-    std::vector<uint32_t> order(K);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        return soffs[a + 1] - soffs[a] > soffs[b + 1] - soffs[b];
-    });
+    const std::vector<uint64_t>& soffs = es.soffs;
+    const std::vector<uint32_t>& ssample = es.ssample;
+    const std::vector<uint32_t>& order = es.order;
+    const uint64_t K = soffs.size() - 1;
+    uint64_t* const d_soffs = es.d_soffs;
+    uint64_t* const d_sbase = es.d_sbase;
+    uint32_t* const d_order = es.d_order;
+    uint32_t* const d_ssample = es.d_ssample;
     const size_t n_rev = m->flat_rev.table.size();
     // replicas of the expected-count array (see estep4_bwd_kernel): up to 256, within 512 MiB
     uint32_t n_rep = 256;
     while (n_rep > 1 && (size_t)n_rep * n_rev * 8 > (512ull << 20)) n_rep >>= 1;
     const size_t abytes = (size_t)(N + K + 128) * 8, ebytes = (size_t)(n_rep + 1) * n_rev * 8 + 256, zbytes = (size_t)K * 8 + 256;
-    const size_t obytes = (size_t)(K + 1) * 8 + 256, ordbytes = (size_t)K * 4 + 256;
     double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr, *d_zarr = nullptr;
     int32_t* d_aexp = nullptr;  // block exponents of alpha (linear-domain kernels)
     const size_t xbytes = (size_t)((N >> 4) + K + 128) * 4;
     // TGX_ESTEP=log keeps the log-domain kernels (A/B timing, tests of both)
     const char* force_log = getenv("TGX_ESTEP");
     const bool linear = m->estep_linear_ok && !(force_log && strcmp(force_log, "log") == 0);
-    uint64_t *d_soffs = nullptr, *d_sbase = nullptr;
-    uint32_t *d_order = nullptr, *d_ssample = nullptr;
     auto cleanup = [&](tgx_status s2) {
         // kernels already queued may still write these buffers: no other handle may take them from the pool yet
         if (s2 != TGX_OK) (void)hipStreamSynchronize(m->stream);
@@ -1905,27 +1950,15 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         pool_free(m->device, d_exp, ebytes);
         pool_free(m->device, d_z, 256);
         pool_free(m->device, d_zarr, zbytes);
-        pool_free(m->device, d_soffs, obytes);
-        pool_free(m->device, d_sbase, obytes);
-        pool_free(m->device, d_order, ordbytes);
-        pool_free(m->device, d_ssample, ordbytes);
         return s2;
     };
     if (pool_alloc(m->device, abytes, (void**)&d_alpha) != hipSuccess ||
         (linear && pool_alloc(m->device, xbytes, (void**)&d_aexp) != hipSuccess) ||
         pool_alloc(m->device, ebytes, (void**)&d_exp) != hipSuccess ||
         pool_alloc(m->device, 256, (void**)&d_z) != hipSuccess ||
-        pool_alloc(m->device, zbytes, (void**)&d_zarr) != hipSuccess ||
-        pool_alloc(m->device, obytes, (void**)&d_soffs) != hipSuccess ||
-        pool_alloc(m->device, obytes, (void**)&d_sbase) != hipSuccess ||
-        pool_alloc(m->device, ordbytes, (void**)&d_order) != hipSuccess ||
-        pool_alloc(m->device, ordbytes, (void**)&d_ssample) != hipSuccess)
+        pool_alloc(m->device, zbytes, (void**)&d_zarr) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (E-step scratch)"));
-    if (hipMemcpyAsync(d_soffs, soffs.data(), (K + 1) * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
-        (K && hipMemcpyAsync(d_sbase, sbase.data(), K * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
-        (K && hipMemcpyAsync(d_order, order.data(), K * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
-        (K && hipMemcpyAsync(d_ssample, ssample.data(), K * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess) ||
-        hipMemsetAsync(d_exp, 0, ebytes, m->stream) != hipSuccess ||
+    if (hipMemsetAsync(d_exp, 0, ebytes, m->stream) != hipSuccess ||
         hipMemsetAsync(d_z, 0, 256, m->stream) != hipSuccess ||
         hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "E-step setup copies failed"));
