@@ -868,22 +868,29 @@ void tgx_host_free(void* p) {
 static tgx_status ensure_encode_tables(tgx_model* m) {
     if (m->encode_tables_ready) return TGX_OK;
     HIP_TRY(hipSetDevice(m->device));
-    if (m->lm <= 32 && m->scores_finite) {
-        tgx::build_tok_hash(m->vocab_bytes.data(), m->vocab_offs.data(), m->vocab_size, &m->tokhash);
-        if (m->tokhash.ok) {
-            const size_t hb = m->tokhash.slots.size() * sizeof(tgx::TokHashEntry);
-            HIP_TRY(hipMalloc(&m->d_tokhash, hb));
-            HIP_TRY(hipMemcpyAsync(m->d_tokhash, m->tokhash.slots.data(), hb, hipMemcpyHostToDevice, m->stream));
-        }
-    }
-    if (m->lm <= 16 && m->scores_finite && m->d_tokhash && m->flat.table.size() < (1u << 23)) {
-        tgx::Trie8 t8;
+    // the bytes -> id table and the 8-byte records are independent: the first is built on a second host thread
+    // while this one builds the second (each ~50 ms at 500 000 tokens)
+    const bool want_hash = m->lm <= 32 && m->scores_finite;
+    const bool want_trie8 = m->lm <= 16 && m->scores_finite && m->flat.table.size() < (1u << 23);
+    std::thread hash_builder;
+    if (want_hash)
+        hash_builder = std::thread([m]() { tgx::build_tok_hash(m->vocab_bytes.data(), m->vocab_offs.data(), m->vocab_size, &m->tokhash); });
+    tgx::Trie8 t8;
+    if (want_trie8) {
         uint32_t max_hot = kE5MaxHot;
         if (const char* e = getenv("TGX_E5_MAX_HOT")) {  // tests: a small table forces the cold-value paths
             const int v = atoi(e);
             if (v >= 0 && v <= (int)kE5MaxHot) max_hot = (uint32_t)v;
         }
         tgx::build_trie8(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), max_hot, kE5MaxHotCold, &t8);
+    }
+    if (hash_builder.joinable()) hash_builder.join();
+    if (want_hash && m->tokhash.ok) {
+        const size_t hb = m->tokhash.slots.size() * sizeof(tgx::TokHashEntry);
+        HIP_TRY(hipMalloc(&m->d_tokhash, hb));
+        HIP_TRY(hipMemcpyAsync(m->d_tokhash, m->tokhash.slots.data(), hb, hipMemcpyHostToDevice, m->stream));
+    }
+    if (want_trie8 && m->d_tokhash) {
         const size_t ns = t8.rec.size();
         HIP_TRY(hipMalloc(&m->d_trie8, ns * sizeof(tgx::Trie8Rec)));
         HIP_TRY(hipMalloc((void**)&m->d_cold_scores, ns * 8));
