@@ -89,6 +89,8 @@ hipError_t pair_count_sort_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t pair_count_sort(void* temp, size_t temp_bytes, const unsigned int* counts_in, unsigned int* counts_out,
                            const unsigned long long* keys_in, unsigned long long* keys_out, uint64_t n,
                            hipStream_t stream);
+hipError_t launch_pair_expand(const unsigned long long* keys, const unsigned int* cnt, uint64_t n, uint32_t shift,
+                              unsigned long long* out_keys, unsigned long long* out_counts, hipStream_t stream);
 constexpr uint32_t kHistMaxVocab = 36864;  // ids whose u32 counters fit one block's LDS (144 KiB)
 hipError_t launch_ids_histogram(const uint32_t* ids, uint64_t n, uint32_t vocab, unsigned long long* out, uint32_t blocks,
                                 hipStream_t stream);

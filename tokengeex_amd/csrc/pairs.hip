@@ -5,6 +5,7 @@
 // the encode kernel: one u64 key (a << 32 | b) per token slot (the last token of a
 // sample gets a sentinel), radix sort (rocPRIM), run-length encode.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include <cstring>
@@ -86,6 +87,24 @@ hipError_t pair_count_sort(void* temp, size_t temp_bytes, const unsigned int* co
                            hipStream_t stream) {
     return rocprim::radix_sort_pairs_desc(temp, temp_bytes, counts_in, counts_out, keys_in, keys_out, (size_t)n, 0, 32,
                                           stream);
+}
+
+// (sorted key, count) -> the ABI's (a << 32 | b, count as u64): the whole table leaves the device in its final form
+__global__ __launch_bounds__(256) void pair_expand_kernel(const unsigned long long* __restrict__ keys, const unsigned int* __restrict__ cnt,
+                                                          uint64_t n, uint32_t shift, unsigned long long* __restrict__ out_keys,
+                                                          unsigned long long* __restrict__ out_counts) {
+    const unsigned long long low = shift < 32 ? (1ull << shift) - 1ull : 0xFFFFFFFFull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = keys[i];
+        out_keys[i] = ((k >> shift) << 32) | (k & low);
+        out_counts[i] = cnt[i];
+    }
+}
+hipError_t launch_pair_expand(const unsigned long long* keys, const unsigned int* cnt, uint64_t n, uint32_t shift,
+                              unsigned long long* out_keys, unsigned long long* out_counts, hipStream_t stream) {
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL(pair_expand_kernel, dim3(blocks), dim3(256), 0, stream, keys, cnt, n, shift, out_keys, out_counts);
+    return hipGetLastError();
 }
 
 // ---- frequency pass of a vocabulary that fits LDS: one private histogram per block -------------------------

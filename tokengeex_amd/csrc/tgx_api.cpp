@@ -1789,11 +1789,6 @@ static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pai
         src_cnt = cnt_out;
         runs = (unsigned int)std::min<uint64_t>(runs, max_pairs);
     }
-    std::vector<unsigned long long> hk(runs ? runs : 1);
-    std::vector<unsigned int> hc(runs ? runs : 1);
-    if (runs && (hipMemcpy(hk.data(), src_keys, (size_t)runs * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                 hipMemcpy(hc.data(), src_cnt, (size_t)runs * 4, hipMemcpyDeviceToHost) != hipSuccess))
-        return cleanup(fail(TGX_ERR_DEVICE, "D2H copy of pair table failed"));
     uint64_t* ok = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
     uint64_t* oc = (uint64_t*)malloc(sizeof(uint64_t) * (runs ? runs : 1));
     if (!ok || !oc) {
@@ -1801,10 +1796,34 @@ static tgx_status count_pairs_impl(tgx_model* m, tgx_corpus* c, uint64_t max_pai
         free(oc);
         return cleanup(fail(TGX_ERR_DEVICE, "out of host memory (pair table of %llu entries)", (unsigned long long)runs));
     }
-    const unsigned long long low = shift < 32 ? (1ull << shift) - 1 : 0xFFFFFFFFull;
-    for (unsigned int i = 0; i < runs; i++) {
-        ok[i] = ((hk[i] >> shift) << 32) | (hk[i] & low);
-        oc[i] = hc[i];
+    if (!max_pairs && runs) {
+        // the whole table (millions of pairs: the multi-GPU merge exchanges it): brought into the ABI's form on the
+        // device and copied straight into the caller's arrays — two zero-filled staging vectors and a host loop
+        // over every pair took three times the kernels' time.  d_sorted and d_keys are free by now.
+        unsigned long long* ek = d_sorted;
+        unsigned long long* ec = d_keys;
+        if (tgx::launch_pair_expand(src_keys, src_cnt, runs, (uint32_t)shift, ek, ec, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess ||
+            copy_sync(ok, ek, (size_t)runs * 8, hipMemcpyDeviceToHost, m->device) != hipSuccess ||
+            copy_sync(oc, ec, (size_t)runs * 8, hipMemcpyDeviceToHost, m->device) != hipSuccess) {
+            free(ok);
+            free(oc);
+            return cleanup(fail(TGX_ERR_DEVICE, "D2H copy of pair table failed"));
+        }
+    } else {
+        std::vector<unsigned long long> hk(runs ? runs : 1);
+        std::vector<unsigned int> hc(runs ? runs : 1);
+        if (runs && (hipMemcpy(hk.data(), src_keys, (size_t)runs * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                     hipMemcpy(hc.data(), src_cnt, (size_t)runs * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+            free(ok);
+            free(oc);
+            return cleanup(fail(TGX_ERR_DEVICE, "D2H copy of pair table failed"));
+        }
+        const unsigned long long low = shift < 32 ? (1ull << shift) - 1 : 0xFFFFFFFFull;
+        for (unsigned int i = 0; i < runs; i++) {
+            ok[i] = ((hk[i] >> shift) << 32) | (hk[i] & low);
+            oc[i] = hc[i];
+        }
     }
     *keys = ok;
     *counts = oc;
