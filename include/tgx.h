@@ -171,8 +171,8 @@ tgx_status tgx_encode_batch(tgx_model *m, const uint8_t *text, const uint64_t *o
                             uint64_t n_samples, double dropout, uint64_t seed, tgx_result **out);
 /* The same with host buffers on both sides: the ids are written to ids_out (room for ids_cap entries; the
  * number of bytes of the batch always suffices) and the exclusive token offsets to offs_out[n_samples + 1].
- * Large batches are cut at sample boundaries into chunks whose upload, kernels and download overlap (three
- * host threads).  Errors as tgx_encode_batch (the lowest failing sample of the batch is reported). */
+ * Large batches are cut at sample boundaries into chunks that go through three stages — upload, kernels,
+ * download — on three host threads and two copy streams, so the link works in both directions beside the kernels.  Errors as tgx_encode_batch (the lowest failing sample of the batch is reported). */
 tgx_status tgx_encode_batch_host(tgx_model *m, const uint8_t *text, const uint64_t *offs, uint64_t n_samples,
                                  double dropout, uint64_t seed, uint32_t *ids_out, uint64_t ids_cap,
                                  uint64_t *offs_out, uint64_t *n_tokens);
@@ -224,8 +224,10 @@ tgx_status tgx_count_pairs_top(tgx_model *m, tgx_corpus *c, uint64_t max_pairs, 
 /* run_e_step — src/prune.rs:64-120 over src/model.rs:34-55 + src/lattice.rs:245-333:
  * each sample cut into <= snippet_len-byte snippets, forward/backward in f64
  * log-space, expected[vocab_size] ACCUMULATED into (host), *logz_sum = sum of z.
- * TGX_ERR_Z_NOT_NORMAL where the reference would panic (expected[] is still
- * filled). */
+ * TGX_ERR_Z_NOT_NORMAL where the reference would panic (nothing of the failed
+ * pass is added to expected[]).  Tokens of up to 16 bytes, and of up to 32 bytes
+ * (vocabularies after `merge`), run the four-snippets-per-wave kernels; longer
+ * ones the generic kernel. */
 tgx_status tgx_estep(tgx_model *m, tgx_corpus *c, uint64_t snippet_len, double dropout,
                      uint64_t seed, double *expected, double *logz_sum);
 
