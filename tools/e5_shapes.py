@@ -1,6 +1,7 @@
 """encode5_kernel by corpus shape and positions per lane: throughput on large corpora of long / short samples,
 and the serial chain of long samples (a corpus of a few 64 KiB samples: each alone on its row)."""
 import os, sys
+os.environ.setdefault("TGX_LONG_THRESHOLD", "0")  # encode5_kernel alone: no long samples to encode6_kernel
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import tokengeex_amd as tgx
