@@ -210,6 +210,7 @@ struct tgx_model {
     uint32_t n_hot = 0, root_base8 = 0;
     bool have_trie8 = false, has_cold = false;
     bool encode_tables_ready = false;  // tokhash / trie8 built and uploaded (ensure_encode_tables)
+    bool tokhash_host_built = false;   // m->tokhash was built beside the forward trie at creation
     double hot_coverage = 0.0;
     int estep_blocks_per_cu = 0;
     KernelTime timed[kMaxTimed] = {};
@@ -873,7 +874,7 @@ static tgx_status ensure_encode_tables(tgx_model* m) {
     const bool want_hash = m->lm <= 32 && m->scores_finite;
     const bool want_trie8 = m->lm <= 16 && m->scores_finite && m->flat.table.size() < (1u << 23);
     std::thread hash_builder;
-    if (want_hash)
+    if (want_hash && !m->tokhash_host_built)
         hash_builder = std::thread([m]() { tgx::build_tok_hash(m->vocab_bytes.data(), m->vocab_offs.data(), m->vocab_size, &m->tokhash); });
     tgx::Trie8 t8;
     if (want_trie8) {
@@ -948,7 +949,29 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
                 for (uint64_t k = ro[i]; k < ro[i + 1]; k++) rev[k] = bytes[o0 + ro[i + 1] - 1 - (k - ro[i])];
             tgx::build_flat_trie(rev.data(), ro.data(), scores, vocab_size, &m->flat_rev);
         });
+    // a model for encode: the bytes -> id table does not depend on the trie and is built beside it
+    std::thread hash_early;
+    if (!(flags & TGX_MODEL_FOR_ESTEP) && vocab_size) {
+        bool finite = true;
+        uint64_t longest = 0;
+        for (uint32_t i = 0; i < vocab_size; i++) {
+            finite = finite && (scores[i] - scores[i] == 0.0);
+            longest = std::max<uint64_t>(longest, offs[i + 1] - offs[i]);
+        }
+        if (finite && longest <= 32) {
+            hash_early = std::thread([m, bytes, offs, vocab_size]() {
+                // (same arguments as ensure_encode_tables: token bytes from offs[0] on, offsets rebased to 0)
+                std::vector<uint64_t> ro(vocab_size + 1);
+                for (uint32_t i = 0; i <= vocab_size; i++) ro[i] = offs[i] - offs[0];
+                tgx::build_tok_hash(bytes + offs[0], ro.data(), vocab_size, &m->tokhash);
+            });
+        }
+    }
     tgx::build_flat_trie(bytes, vocab_size ? offs : zero_offs, scores, vocab_size, &m->flat);
+    if (hash_early.joinable()) {
+        hash_early.join();
+        m->tokhash_host_built = true;
+    }
     if (rev_builder.joinable()) {
         rev_builder.join();
         m->rev_host_built = true;
