@@ -138,6 +138,17 @@ def test_flat_trie_large_vocab_builds_fast():
     st = ft.stats()
     assert dt < 20.0, dt
     assert st["fill"] > 0.6, st
+    # configs[3]'s 500 000-entry vocabulary (628 436 nodes): 0.3 s on the build container since single-child nodes
+    # keep a first candidate block per edge byte (1.35 s before: the scan over blocks with free slots but claimed bases)
+    from util import load_vocab_500k
+    toks5, scores5 = load_vocab_500k()
+    packed = _lib.Packed.of(toks5)
+    t = time.time()
+    ft5 = _lib.FlatTrie(packed, scores5)
+    dt5 = time.time() - t
+    st5 = ft5.stats()
+    assert dt5 < 5.0, dt5
+    assert st5["n_nodes"] == 628436 and st5["fill"] > 0.7, st5
 
 
 def test_special_splitter_kats(golden_dir):
