@@ -35,9 +35,12 @@ def main() -> None:
     ap.add_argument("--max-token-length", type=int, default=16)
     ap.add_argument("--kind", default="mixed", choices=["mixed", "ascii"])
     ap.add_argument("--max-sample-len", type=int, default=65536, help="longest sample of the synthetic corpus, bytes")
+    ap.add_argument("--vocab-slice-mb", type=int, default=64,
+                    help="slice of the mixed corpus the vocabulary is built over: 64 = SURVEY.md section 8(d)'s (the committed "
+                         "32 000- and 65 536-entry vocabularies); anything else is built here over at most 8 MiB")
     ap.add_argument("--distinct-scores", action="store_true",
-                    help="give every token its own score (as after an M-step; the default vocabulary scores tokens by "
-                         "integer counts and has ~2 000 distinct values)")
+                    help="give every token its own score (as after an M-step or merge: any trained vocabulary; the "
+                         "generate-style default scores tokens by integer counts: 9 652 distinct values at 32 000 entries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive tgx_encode_batch measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
@@ -91,10 +94,18 @@ def main() -> None:
 
     # ---- workload: same vocabulary on every rank, a different corpus shard per rank
     t0 = time.time()
-    vflat, _ = synth.make_corpus(4 << 20, args.kind, seed_offset=0)
-    toks, scores = synth.build_vocab(vflat[: 2 << 20], args.vocab, args.max_token_length)
+    # vocabulary: SURVEY.md section 8(d)'s — the generate stand-in over a fixed 64 MiB slice of the mixed corpus,
+    # committed (tests/golden/vocab_32000.npz, vocab_65536.npz) — or, for other shapes, built here over a small slice
+    if args.vocab_slice_mb == 64 and args.vocab in (32000, 65536) and args.max_token_length == 16:
+        toks, scores, slice_mib = synth.load_spec_vocab(args.vocab)
+    else:
+        slice_mib = min(args.vocab_slice_mb, 8)
+        vflat, _ = synth.make_corpus(max(4, slice_mib) << 20, "mixed", seed_offset=0)
+        toks, scores = synth.build_vocab(vflat[: slice_mib << 20], args.vocab, args.max_token_length)
+    scores = np.asarray(scores, np.float64)
     if args.distinct_scores:
-        scores = np.asarray(scores, np.float64) + np.random.default_rng(5).uniform(-0.4, 0.4, len(toks))
+        scores = scores + np.random.default_rng(5).uniform(-0.4, 0.4, len(toks))
+    n_values = int(np.unique(scores).size)
     flat, offs = synth.make_corpus(args.size_mb << 20, args.kind, max_len=args.max_sample_len, seed_offset=1000 + rank)
     n_bytes, n_samples = int(flat.size), int(offs.size - 1)
     model = tgx.NativeModel(toks, scores, device=dev)
@@ -177,14 +188,14 @@ def main() -> None:
         # cannot be read inside this process): the committed figure of the profiled build, with its source
         # named, and only for the workload it was taken on; null otherwise
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-        if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length, args.max_sample_len, args.distinct_scores) == (1024, 32000, "mixed", 16, 65536, False):
+        tpath = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+        if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length, args.max_sample_len, args.distinct_scores, args.vocab_slice_mb) == (1024, 32000, "mixed", 16, 65536, False, 64):
             with open(tpath) as f:
                 tj = json.load(f)
             enc = lambda names: {k.split("<")[0] for k in names if k.startswith("encode")}
             if enc(tj.get("kernels", {})) == enc(per_step):  # same encode kernels as this build
                 traffic = tj.get("hbm_bytes_per_pass_corrected")
-                traffic_source = f"profiles/r02/pmc_traffic.json ({tj.get('commit', '?')})"
+                traffic_source = f"profiles/r03/pmc_traffic.json ({tj.get('commit', '?')})"
         out = {
             "metric": "MB/s raw bytes encoded (and tokens/s) at 32K/64K vocab, 1/2/4/8 GPUs",
             "value": round(mb_s, 2),
@@ -199,10 +210,13 @@ def main() -> None:
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"encode_ordinary_batch, {args.vocab} vocab (max token {args.max_token_length} B), "
-                            f"{'every token its own score, ' if args.distinct_scores else ''}"
+                "workload": f"encode_ordinary_batch, {args.vocab} vocab (max token {args.max_token_length} B; generate stand-in over a "
+                            f"{slice_mib} MiB slice of the mixed corpus; {n_values} distinct score values"
+                            f"{': every token its own, as after an M-step' if args.distinct_scores else ''}; "
+                            f"{model.last_encode_hot_values()} of them in the kernel's LDS copy), "
                             f"{args.size_mb} MiB {args.kind} corpus per GPU (samples <= {args.max_sample_len} B), "
                             f"ids bit-exact vs CPU oracle",
+                "vocab_slice_mib": slice_mib, "distinct_score_values": n_values, "lds_score_values": model.last_encode_hot_values(),
                 "bytes_per_gpu": n_bytes, "samples_per_gpu": n_samples, "tokens_per_gpu": int(n_tokens),
                 "parallelism": f"dp{world} (samples sharded, no collective)",
             },

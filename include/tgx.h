@@ -144,10 +144,13 @@ uint64_t tgx_flat_trie_search(const tgx_flat_trie *t, const uint8_t *s, uint64_t
 void tgx_flat_trie_stats(const tgx_flat_trie *t, uint64_t *n_slots, uint64_t *n_nodes,
                          uint32_t *max_token_len);
 /* The same search over the 8-byte label-checked records encode5_kernel walks (built from the same slot
- * assignment: the walk keeps only `base` and compares a record's label with the text byte), plus figures of
- * its score table: *n_hot distinct score values in the table of at most max_hot, *n_cold terminal slots whose
- * value is outside it, *hot_coverage the expected share of matches the table serves.  Any out pointer may be
- * NULL.  Returns the number of matches, or UINT64_MAX when the records cannot be built (>= 2^23 slots). */
+ * assignment: the walk keeps only `base`, compares a record's label with the text byte and ends without a
+ * probe where the node's child mask rules the next byte out), plus figures of the score table for a copy of
+ * max_hot values in LDS: *n_hot = values in that copy (ranks 1..n_hot of the vocabulary's distinct score
+ * values), *n_cold terminal slots whose value is outside it (read from HBM / L2 by the kernels),
+ * *hot_coverage the expected share of matches the copy serves.  Any out pointer may be NULL.  Returns the
+ * number of matches, or UINT64_MAX when the records cannot be built (more than 65 535 distinct score values,
+ * or >= 2^24 slots). */
 uint64_t tgx_flat_trie_search8(const tgx_flat_trie *t, const uint8_t *bytes, const uint64_t *offs,
                                const double *scores, uint32_t max_hot, const uint8_t *s, uint64_t n,
                                uint32_t *ids, uint32_t *lens, uint64_t cap, uint32_t *n_hot,
@@ -280,6 +283,12 @@ uint32_t tgx_last_encode_waves_per_cu(const tgx_model *m);
 uint64_t tgx_last_encode_redo_samples(const tgx_model *m);
 /* samples of the last encode pass that had a block of their own (the long-sample kernel) */
 uint64_t tgx_last_encode_long_samples(const tgx_model *m);
+/* distinct score values of the vocabulary as the rows5 encode kernels rank them (0: the model has no 8-byte
+ * records — tokens longer than 16 bytes, non-finite scores, more than 65 535 distinct values — or has not
+ * encoded yet when it was created for E-step passes), and how many of them the last encode5_kernel launch
+ * kept in its block's LDS (the rest are read from L2 by the relaxing lanes). */
+uint32_t tgx_model_score_values(const tgx_model *m);
+uint32_t tgx_last_encode_hot_values(const tgx_model *m);
 
 /* ---- dropout ---------------------------------------------------------------
  * The reference draws rand::random::<f64>() from an unseeded thread RNG

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the library honours its kernel / geometry switches (TGX_PATH, TGX_PPL, TGX_E5_HOT, ...) only in processes that
+# opt in: the tests force every kernel family against the oracle
+os.environ.setdefault("TGX_KNOBS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
-"""GPU parity of encode5_kernel's score-table paths (csrc/encode5.hip): values in the LDS table, cold values
-through the per-wave pool, and pool overflow with the samples concerned redone by encode4_kernel — all
-bit-exact against the CPU oracle (reference src/model.rs:59-129)."""
+"""GPU parity of encode5_kernel / encode6_kernel (csrc/encode5.hip): score values by rank — the hottest in the
+block's LDS, the others read from L2 by the relaxing lane (COLD builds) —, child masks in the trie records, the
+long-sample kernel; all bit-exact against the CPU oracle (reference src/model.rs:59-129)."""
 import numpy as np
 import pytest
 
@@ -18,72 +18,77 @@ def _distinct_scores(scores, rng):
     return np.asarray(scores, np.float64) - rng.random(len(scores)) * 1e-3
 
 
-@pytest.mark.parametrize("max_hot", ["6600", "2000", "300"])
-def test_cold_values_go_through_the_pool(monkeypatch, max_hot):
-    """8 000 tokens with 8 000 distinct scores and a table of 6 600 / 2 000 / 300 values: the rest are fetched
-    from HBM into the wave's pool while the walk goes on."""
+@pytest.mark.parametrize("hot", ["6600", "2000", "300", "0"])
+def test_values_outside_the_lds_copy_are_read_by_the_relaxing_lane(monkeypatch, hot):
+    """8 000 tokens with 8 000 distinct scores and an LDS copy of 6 600 / 2 000 / 300 / 0 values: the relaxing lane
+    reads the others from the table in HBM / L2; nothing is redone, no other encode kernel runs."""
     rng = np.random.default_rng(7)
     flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 8000, 16, seed_offset=11, max_len=30000)
     scores = _distinct_scores(scores, rng)
-    monkeypatch.setenv("TGX_E5_MAX_HOT", max_hot)
-    monkeypatch.setenv("TGX_PATH", "rows5")
+    monkeypatch.setenv("TGX_E5_HOT", hot)
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
     assert_same_encoding(nat, ora, flat, offs)
-    assert "encode5_kernel" in nat.last_kernel_times()
+    kt = nat.last_kernel_times()
+    assert "encode5_kernel" in kt and "encode4_kernel" not in kt and nat.last_encode_redo_samples() == 0
+    assert nat.score_values() == 8000 and nat.last_encode_hot_values() == int(hot)
     assert_same_encoding(nat, ora, flat, offs, dropout=0.25, seed=3)
-    for ppl in ("2", "4"):
+    for ppl in ("1", "2"):
         monkeypatch.setenv("TGX_PPL", ppl)
         assert_same_encoding(nat, ora, flat, offs)
 
 
-def test_pool_overflow_redoes_only_the_samples_concerned(monkeypatch):
-    """A table of 8 values: nearly every match is cold, a block of 64 positions needs far more than the 64 pool
-    entries of its wave, so the samples are redone by encode4_kernel; ids still bit-exact; a model whose values
-    all fit never syncs for a redo list."""
-    rng = np.random.default_rng(8)
-    flat, offs, toks, scores = corpus_and_vocab(1 << 20, "mixed", 5000, 16, seed_offset=12, max_len=8000)
-    scores = _distinct_scores(scores, rng)
-    monkeypatch.setenv("TGX_PATH", "rows5")
-    monkeypatch.setenv("TGX_E5_MAX_HOT", "8")
-    monkeypatch.setenv("TGX_E5_POOL", "64")  # the default geometry gives a wave as many entries as LDS allows
-    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
-    assert_same_encoding(nat, ora, flat, offs)
-    kt = nat.last_kernel_times()
-    assert "encode5_kernel" in kt and "encode4_kernel" in kt
-    assert nat.last_encode_redo_samples() > 0
-    assert_same_encoding(nat, ora, flat, offs, dropout=0.4, seed=9)
-    monkeypatch.delenv("TGX_E5_MAX_HOT")
-    monkeypatch.delenv("TGX_E5_POOL")
-    nat2 = tgx.NativeModel(toks, scores)
-    assert_same_encoding(nat2, ora, flat, offs)
-    assert "encode4_kernel" not in nat2.last_kernel_times() and nat2.last_encode_redo_samples() == 0
-
-
-def test_default_path_and_coverage_rule(monkeypatch):
-    """generate-style vocabularies (integer counts: a few thousand distinct values) run encode5_kernel by
-    default; a vocabulary of 60 000 distinct values, of which the table holds a small share, stays on
-    encode4_kernel unless forced."""
+def test_which_kernel_serves_which_vocabulary(monkeypatch):
+    """generate-style vocabularies (scores are logs of integer counts: a few thousand distinct values) AND
+    vocabularies in which every token has its own score (after an M-step or merge: src/prune.rs:143-151,
+    src/merge.rs:102 — any trained vocabulary) run encode5_kernel: the first with all values in LDS, the second
+    with the hottest in LDS and the rest read from L2.  More than 65 535 distinct values (a match index is a 16-bit
+    rank) leave encode4_kernel."""
     flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 32000, 16, seed_offset=13)
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
     assert_same_encoding(nat, ora, flat, offs)
-    assert "encode5_kernel" in nat.last_kernel_times()
+    kt = nat.last_kernel_times()
+    assert "encode5_kernel" in kt and "encode4_kernel" not in kt
+    assert 0 < nat.score_values() == nat.last_encode_hot_values() < 16000   # every value in LDS
     rng = np.random.default_rng(9)
-    flat2, offs2 = synth.make_corpus(6 << 20, "mixed", seed_offset=14)
-    toks2, scores2 = synth.build_vocab(flat2, 60000, 16)
-    scores2 = -rng.random(len(toks2)) * 12.0 - 1.0          # flat random scores: the table covers ~11 % of the mass
-    nat2, ora2 = tgx.NativeModel(toks2, scores2), orc.OracleModel(toks2, scores2)
-    sub_f, sub_o = flat2[: int(offs2[150])], offs2[:151]
-    assert_same_encoding(nat2, ora2, sub_f, sub_o)
+    sc2 = _distinct_scores(scores, rng)
+    nat2, ora2 = tgx.NativeModel(toks, sc2), orc.OracleModel(toks, sc2)
+    assert_same_encoding(nat2, ora2, flat, offs)
+    kt = nat2.last_kernel_times()
+    assert "encode5_kernel" in kt and "encode4_kernel" not in kt and nat2.last_encode_redo_samples() == 0
+    assert nat2.score_values() == len(set(sc2.tolist())) > nat2.last_encode_hot_values() >= 3000
+    # TGX_PATH=rows4 still forces round 1's kernel (A/B timing): same ids
+    monkeypatch.setenv("TGX_PATH", "rows4")
+    assert_same_encoding(nat2, ora2, flat, offs)
     assert "encode4_kernel" in nat2.last_kernel_times() and "encode5_kernel" not in nat2.last_kernel_times()
-    monkeypatch.setenv("TGX_PATH", "rows5")
-    assert_same_encoding(nat2, ora2, sub_f, sub_o)
-    assert "encode5_kernel" in nat2.last_kernel_times()
+    monkeypatch.delenv("TGX_PATH")
+    # 70 000 tokens with 70 000 distinct scores: no 8-byte records
+    flat3, offs3 = synth.make_corpus(6 << 20, "mixed", seed_offset=14)
+    toks3, scores3 = synth.build_vocab(flat3, 70000, 16)
+    scores3 = -rng.random(len(toks3)) * 12.0 - 1.0
+    nat3, ora3 = tgx.NativeModel(toks3, scores3), orc.OracleModel(toks3, scores3)
+    sub_f, sub_o = flat3[: int(offs3[150])], offs3[:151]
+    assert_same_encoding(nat3, ora3, sub_f, sub_o)
+    assert "encode4_kernel" in nat3.last_kernel_times() and "encode5_kernel" not in nat3.last_kernel_times()
+    assert nat3.score_values() == 0
+
+
+def test_exactly_65535_distinct_values_still_take_the_rank_kernel():
+    """Ranks are 16 bits with 0 for "no token": 65 535 values is the last vocabulary the rows5 kernels serve."""
+    rng = np.random.default_rng(31)
+    flat, offs = synth.make_corpus(6 << 20, "mixed", seed_offset=15)
+    toks, _ = synth.build_vocab(flat, 65535, 16)
+    assert len(toks) == 65535
+    scores = -(np.arange(65535, dtype=np.float64) * 1e-4 + 1.0)
+    rng.shuffle(scores)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    sub_f, sub_o = flat[: int(offs[200])], offs[:201]
+    assert_same_encoding(nat, ora, sub_f, sub_o)
+    assert "encode5_kernel" in nat.last_kernel_times() and nat.score_values() == 65535
 
 
 def test_edge_bytes_and_block_boundaries(monkeypatch):
     """Bytes 0xFE / 0xFF (the label check's reserved base values), tokens made of them, samples around the
     multiples of 16 and 64, unreachable ends, empty samples."""
-    monkeypatch.setenv("TGX_PATH", "rows5")
     toks = [bytes([c]) for c in range(255)] + [b"\xff\xfe", b"\xfe\xfe\xfe", b"\xfe" * 16, b"ab", b"abc" * 5, b"\x00\x00"]
     scores = np.array([-6.0] * 255 + [-2.0, -3.0, -20.0, -7.0, -9.5, -1.0])
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
@@ -126,46 +131,38 @@ def test_long_sample_kernel_walkers_and_relaxer(monkeypatch, threshold):
     assert e.value.sample == 1 and str(e.value) == "no path to position 6201/6201"
 
 
-@pytest.mark.parametrize("max_hot,pool", [("2000", None), ("300", None), ("40", "16")])
-def test_long_sample_kernel_with_cold_values(monkeypatch, max_hot, pool):
-    """encode6_kernel's walkers with score values outside the table: each ring slot has a pool, filled after the
-    walk in one batch of loads; a slot that runs out flags the sample, which the redo pass encodes."""
+@pytest.mark.parametrize("hot", ["2000", "300", "0"])
+def test_long_sample_kernel_with_values_outside_its_lds_copy(monkeypatch, hot):
+    """encode6_kernel's relaxing wave with score values outside the LDS copy: read from L2 a quarter group ahead
+    of the steps that use them; nothing is redone."""
     rng = np.random.default_rng(21)
     flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 8000, 16, seed_offset=54, max_len=30000)
     scores = _distinct_scores(scores, rng)
-    monkeypatch.setenv("TGX_PATH", "rows5")
-    monkeypatch.setenv("TGX_E5_MAX_HOT", max_hot)
+    monkeypatch.setenv("TGX_E5_HOT", hot)
     monkeypatch.setenv("TGX_LONG_THRESHOLD", "2000")
-    if pool:
-        monkeypatch.setenv("TGX_E5_POOL", pool)
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
     assert_same_encoding(nat, ora, flat, offs)
     kt = nat.last_kernel_times()
-    assert "encode6_kernel" in kt and "encode5_kernel" in kt and nat.last_encode_long_samples() > 0
-    if pool:
-        assert nat.last_encode_redo_samples() > 0 and "encode4_kernel" in kt
+    assert "encode6_kernel" in kt and "encode5_kernel" in kt and "encode4_kernel" not in kt and nat.last_encode_long_samples() > 0
+    assert nat.last_encode_redo_samples() == 0
     assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=11)
 
 
-def test_vocabulary_with_distinct_scores_takes_encode4_by_default(monkeypatch):
-    """After an M-step every token has its own score (src/prune.rs:143-151): more values than the LDS table holds.
-    Such a model runs encode4_kernel (16-byte records, f64 scores in the match buffer) unless forced."""
+def test_vocabulary_with_distinct_scores_by_default(monkeypatch):
+    """After an M-step every token has its own score (src/prune.rs:143-151): by default such a model runs
+    encode5_kernel with the LDS copy that fits, and its long samples go to encode6_kernel where the estimate says
+    so (a 16 MiB batch of samples <= 64 KiB is bound by the serial chains of its longest samples)."""
     rng = np.random.default_rng(22)
     flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 12000, 16, seed_offset=55)
     nat, ora = tgx.NativeModel(toks, _distinct_scores(scores, rng)), orc.OracleModel(toks, _distinct_scores(scores, np.random.default_rng(22)))
     assert_same_encoding(nat, ora, flat, offs)
     kt = nat.last_kernel_times()
-    assert "encode4_kernel" in kt and "encode5_kernel" not in kt and nat.last_encode_redo_samples() == 0
-    # ... and its long samples go to encode6_kernel (the build with cold-value pools) where the estimate says so:
-    # a 16 MiB batch of samples <= 64 KiB is bound by the serial chains of its longest samples
+    assert "encode5_kernel" in kt and "encode4_kernel" not in kt and nat.last_encode_redo_samples() == 0
+    assert nat.last_encode_hot_values() < nat.score_values() == 12000
     f2, o2 = synth.make_corpus(16 << 20, "mixed", seed_offset=56)
     assert_same_encoding(nat, ora, f2, o2)
     kt = nat.last_kernel_times()
-    assert "encode6_kernel" in kt and "encode4_kernel" in kt and 0 < nat.last_encode_long_samples() < o2.size - 1
-    monkeypatch.setenv("TGX_E5_POOL", "8")          # pools this small overflow: those samples come back to encode4
-    monkeypatch.setenv("TGX_LONG_THRESHOLD", "3000")
-    assert_same_encoding(nat, ora, f2, o2)
-    assert nat.last_encode_redo_samples() > 0
+    assert "encode6_kernel" in kt and "encode5_kernel" in kt and 0 < nat.last_encode_long_samples() < o2.size - 1
     assert_same_encoding(nat, ora, f2, o2, dropout=0.2, seed=4)
 
 

@@ -223,6 +223,36 @@ def test_estep_long_token_overflow_list_falls_back_to_the_generic_kernel():
     assert abs(gz - wz) <= 1e-12 * abs(wz)
 
 
+def test_estep_long_token_overflow_of_the_backward_list_alone_falls_back():
+    """The backward kernel counts matches of 17..32 bytes by END position (windows of 16 counted from the snippet's
+    end), the forward kernel by START position: 80 long matches whose ends share one backward window while their
+    starts straddle two forward windows (39 + 41, the list holds 62) overflow the backward list only.  The forward
+    kernel raises nothing, the backward kernel does, and the pass must be discarded and redone by the generic
+    kernel — not returned with the excess matches dropped."""
+    n, j = 160, 4
+    region = bytes(range(0x30, 0x30 + 48))            # 48 distinct bytes at [16 j - 32, 16 j + 16)
+    text = bytearray(b"." * n)
+    text[16 * j - 32:16 * j + 16] = region
+    text = bytes(text)
+    long_toks = [text[q - L:q] for q in range(16 * j + 1, 16 * j + 17) for L in (17, 21, 25, 29, 32)]
+    assert len(set(long_toks)) == 80
+    starts = [q - L for q in range(16 * j + 1, 16 * j + 17) for L in (17, 21, 25, 29, 32)]
+    per_fwd_window = np.bincount(np.array(starts) // 16)
+    assert per_fwd_window.max() <= 62 and len(long_toks) > 62  # forward lists fit, the backward one does not
+    toks = [bytes([b]) for b in range(256)] + long_toks
+    scores = np.concatenate([np.full(256, -5.0), -3.0 - 0.01 * np.arange(80)])
+    nat, ora = _pair(toks, scores)
+    flat, offs = tgx.pack([text])
+    got, gz = nat.estep(tgx.NativeCorpus(flat, offs), 81920)
+    kt = nat.last_kernel_times()
+    assert "estep4l_bwd_kernel" in kt and "estep_kernel" in kt, kt  # the backward kernel ran, then the fallback
+    st, want, wz, _ = ora.estep_flat(flat, offs, 81920, threads=1)
+    assert st == orc.OK
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=ATOL)
+    assert np.array_equal(got != 0, want != 0)
+    assert abs(gz - wz) <= 1e-12 * abs(wz)
+
+
 def test_estep_falls_back_to_log_domain_when_a_position_has_no_incoming_token():
     """A text byte that is no token leaves a position without an incoming token (lattice.rs:255: it then
     counts as log-probability 0.0), which the linear-domain kernels cannot express: their forward kernel

@@ -85,6 +85,8 @@ SYMBOLS = {
     "tgx_last_algorithmic_bytes": (_u64, [_vp]),
     "tgx_last_encode_waves_per_cu": (_u32, [_vp]),
     "tgx_last_encode_redo_samples": (_u64, [_vp]),
+    "tgx_model_score_values": (_u32, [_vp]),
+    "tgx_last_encode_hot_values": (_u32, [_vp]),
     "tgx_last_encode_long_samples": (_u64, [_vp]),
 }
 
@@ -516,6 +518,12 @@ class NativeModel:
 
     def last_encode_redo_samples(self) -> int:
         return lib.tgx_last_encode_redo_samples(self._h)
+
+    def score_values(self) -> int:
+        return lib.tgx_model_score_values(self._h)
+
+    def last_encode_hot_values(self) -> int:
+        return lib.tgx_last_encode_hot_values(self._h)
 
     def last_encode_long_samples(self) -> int:
         return lib.tgx_last_encode_long_samples(self._h)

@@ -7,15 +7,17 @@
 //   * 8-byte label-checked trie records (trie_build.h: Trie8Rec).  A walk keeps only `base`; a step is one
 //     8-byte gather {label | terminal | next base, score reference} (0.9 cycles per lane, measured:
 //     profiles/r02/a_gather_8byte_records.txt) and one compare of the label with the text byte.
-//   * scores are not carried through the match buffer.  The distinct score VALUES of the vocabulary (a few
-//     thousand for generate-style vocabularies, which score tokens by integer counts) sit in a table in
-//     the block's LDS, ordered by how often their tokens are expected to match; the match buffer holds 2-byte
-//     LDS addresses of table entries ("no token" = the address of a -inf entry), 2 KiB per wave and 64
-//     positions instead of 8 KiB.  A token whose value did not make the table ("cold": COLD builds) gets an
-//     entry of a per-wave pool — the walk leaves the trie slot there and one batch of loads after the walk
-//     replaces the slots by the scores; a wave whose pool runs out marks the samples it is working on, and the
-//     host redoes exactly those with encode4_kernel.  (Models with cold values run encode4_kernel by default:
-//     tgx_api.cpp; the COLD builds serve encode6_kernel's long samples and TGX_PATH=rows5.)
+//   * scores are not carried through the match buffer.  The distinct score VALUES of the vocabulary are ranked
+//     by how often their tokens are expected to match (trie_build.h: Trie8) and a match is the 16-bit RANK of its
+//     value ("no token" = rank 0 = a -inf entry): 2 KiB per wave and 64 positions instead of 8 KiB.  The first
+//     n_hot values sit in a table in the block's LDS; round 3: a rank beyond the table is read from the same
+//     table in HBM / L2 by the RELAXING lane (COLD builds: one exec-masked 8-byte load per cold match, issued with
+//     the LDS reads of its group).  Every vocabulary with at most 65 535 distinct values runs this kernel — after
+//     an M-step every token has its own (src/prune.rs:143-151) — and nothing can overflow: round 2 sent cold
+//     values through per-wave pools in LDS whose overflow cost a second pass over the samples concerned.
+//   * round 3: child masks.  A record carries a 16-bit mask of the byte classes (byte >> 4) its node has children
+//     in; a walk whose next byte is ruled out ends without the failing probe that used to end it (3.46 -> 2.55
+//     gathers per position below the root level).
 //   * the PPL walks of a lane are staggered (Walk5), and the relaxation runs on relax5_step (device_common.h).
 //
 // Same candidate order and strict '>' as encode4_kernel, so the back-pointer bytes and the per-sample status
@@ -38,95 +40,49 @@ namespace tgx {
 constexpr uint32_t kE5RowStride = 512;
 constexpr uint32_t kE5GroupBytes = 4 * kE5RowStride;  // 2048
 
-// sref of a record (trie_build.h: Trie8Rec): bit 31 terminal, bit 30 cold, low bits LDS byte offset / slot
-constexpr uint32_t kSrefCold = 0x40000000u;
-
 template <int PPL>
 struct WalkCtx {
     const uint2* __restrict__ trie;
-    const uint2* rootc;
     unsigned char* smem;
-    const double* __restrict__ cold_scores;
-    uint32_t root_base, pool_entries, pool_off, s, flags, l32;
+    uint32_t s, l32;
     double dropout;
     uint64_t seed;
 };
 
 // ---- the trie walks of a lane (PPL start positions), unrolled over the depth D by template recursion (with
-// its early exit and the wave-wide pool allocation inside, hipcc's unroller gives up on the plain loop and the
-// text bytes end up selected by v_cndmask chains).  The PPL walks are STAGGERED: a level consumes the record of
-// walk g and at once requests walk g's next record, so while one walk's record is examined (about 25
-// instructions) the gathers of the other walks are in flight (vector loads return in order: the wait for walk g's
-// record leaves the PPL - 1 younger ones outstanding).  With all gathers of a depth issued together and waited
-// for together a step of two walks took 890 cycles against 540 for one.
-// COLD = false is the build for vocabularies whose score values all fit the LDS table: no pool code at all.
+// its early exit inside, hipcc's unroller gives up on the plain loop and the text bytes end up selected by
+// v_cndmask chains).  The PPL walks are STAGGERED: a level consumes the record of walk g and at once requests
+// walk g's next record, so while one walk's record is examined (about 25 instructions) the gathers of the other
+// walks are in flight (vector loads return in order: the wait for walk g's record leaves the PPL - 1 younger ones
+// outstanding).  With all gathers of a depth issued together and waited for together a step of two walks took
+// 890 cycles against 540 for one.
 // (Every lane issues every gather, finished walks from slot 0: a load that only some paths issue would force
 // the compiler to wait for ALL outstanding loads at every use — in-order counters cannot name a load that may
 // not exist — and the stagger would be lost.  For the same reason the hottest slots are NOT read from an LDS
 // copy: tried, 2 % at best, a step still waits for its slowest lane, which goes to L2.)
-
-// pool entries [0, cnt) hold trie slots (low dword): overwrite each with cold_scores[slot], four batches of 64
-// loads in flight at a time
-__device__ __forceinline__ void fetch_cold_scores(unsigned char* pool, uint32_t cnt, uint32_t lane, const double* __restrict__ cold_scores) {
-    for (uint32_t e0 = 0; e0 < cnt; e0 += 256u) {
-        uint32_t slot[4];
-        double v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t e = e0 + 64u * k + lane;
-            slot[k] = e < cnt ? *reinterpret_cast<const uint32_t*>(pool + e * 8u) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = cold_scores[slot[k]];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t e = e0 + 64u * k + lane;
-            if (e < cnt) *reinterpret_cast<double*>(pool + e * 8u) = v[k];
-        }
-    }
-}
-
-template <bool DROPOUT, bool COLD, int PPL, int D>
+template <bool DROPOUT, int PPL, int D>
 struct Walk5 {
     // rec[g], c[g]: record and text byte of depth D of walk g (the load may still be in flight)
     static __device__ __forceinline__ void run(const WalkCtx<PPL>& W, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
                                                const uint32_t (&pg)[PPL], const uint32_t (&wlane)[PPL], bool (&alive)[PPL],
-                                               uint2 (&rec)[PPL], uint32_t (&c)[PPL], uint32_t& pool_cnt) {
+                                               uint2 (&rec)[PPL], uint32_t (&c)[PPL]) {
         constexpr int d = D;
         bool any = false;
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
             alive[g] = alive[g] && ((rec[g].x & 0xFFu) == c[g]);
-            bool term = alive[g] && (int32_t)rec[g].y < 0;
+            const uint32_t rank = rec[g].y & 0xFFFFu;  // 0: no token ends here
+            bool term = alive[g] && rank != 0u;
             const uint32_t base = rec[g].x >> 8;
             if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
                 if (term && d >= 1) term = W.dropout < dropout_u01(W.seed, W.s, pg[g], (uint32_t)d + 1u);
             }
-            uint32_t ref = rec[g].y;
-            if (COLD) {
-                const bool cold = term && (ref & kSrefCold) != 0u;
-                const uint64_t cm = __builtin_amdgcn_ballot_w64(cold);
-                if (cm != 0) {  // wave-uniform
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                    const uint32_t e = pool_cnt + rank;
-                    pool_cnt += (uint32_t)__builtin_popcountll(cm);
-                    if (cold) {
-                        if (e < W.pool_entries) {  // the entry holds the SLOT for now: fetch_cold_scores() after the walk
-                            const uint32_t at = W.pool_off + e * 8u;
-                            *reinterpret_cast<uint32_t*>(W.smem + at) = ref & 0x3FFFFFFFu;
-                            ref = at;
-                        } else {
-                            ref = 0u;  // dropped: pool_cnt > pool_entries, the samples of this wave are redone
-                        }
-                    }
-                }
-            }
-            if (term) *reinterpret_cast<uint16_t*>(W.smem + (wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u))) = (uint16_t)ref;
-            // this walk's next record
+            if (term) *reinterpret_cast<uint16_t*>(W.smem + (wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u))) = (uint16_t)rank;
+            // this walk's next record — unless the node has no child in the next byte's class (child mask)
             if (D + 1 < 16) {
                 constexpr int e = D + 1 < 16 ? D + 1 : 15;
-                alive[g] = alive[g] && ((uint32_t)e < maxd[g]);
                 c[g] = (bytes[g][e >> 2] >> ((e & 3) * 8)) & 0xFFu;
+                alive[g] = alive[g] && ((uint32_t)e < maxd[g]) && (((rec[g].y >> 16) >> (c[g] >> 4)) & 1u) != 0u;
                 rec[g] = W.trie[alive[g] ? (base ^ c[g]) : 0u];
             } else {
                 alive[g] = false;
@@ -134,15 +90,41 @@ struct Walk5 {
             any = any || alive[g];
         }
         if (__builtin_amdgcn_ballot_w64(any) == 0) return;
-        Walk5<DROPOUT, COLD, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pool_cnt);
+        Walk5<DROPOUT, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
     }
 };
-template <bool DROPOUT, bool COLD, int PPL>
-struct Walk5<DROPOUT, COLD, PPL, 16> {
+template <bool DROPOUT, int PPL>
+struct Walk5<DROPOUT, PPL, 16> {
     static __device__ __forceinline__ void run(const WalkCtx<PPL>&, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL],
                                                const uint32_t (&)[PPL], const uint32_t (&)[PPL], bool (&)[PPL], uint2 (&)[PPL],
-                                               uint32_t (&)[PPL], uint32_t&) {}
+                                               uint32_t (&)[PPL]) {}
 };
+
+// The score values of N consecutive steps (from step `first`) of a lane, whose sixteen match indices are the 16-bit
+// ranks in iw[8]: rank * 8 is the byte offset of the value in the table.  The LDS copy holds the first hot_bytes of
+// the table; COLD builds (vocabularies with more values than the copy holds) read the others from the table in HBM /
+// L2 under the cold lanes' EXEC mask.  (The LDS reads are unconditional, at clamped addresses, and exist before the
+// conditional loads — the empty asm: written as `hot ? lds : hbm`, or with the LDS read sinkable, the compiler
+// merges the two into one FLAT load of a selected address, which goes through the texture path for every lane.)
+template <bool COLD, int N>
+__device__ __forceinline__ void e5_scores(const unsigned char* smem, const unsigned char* __restrict__ values, const uint32_t (&iw)[8],
+                                          int first, uint32_t hot_bytes, double (&sv)[N]) {
+    uint32_t a[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int v = first + u;
+        a[u] = (v & 1) ? ((iw[v >> 1] >> 13) & 0x7FFF8u) : ((iw[v >> 1] << 3) & 0x7FFF8u);
+        sv[u] = *reinterpret_cast<const double*>(smem + (COLD ? (a[u] < hot_bytes ? a[u] : hot_bytes) : a[u]));
+    }
+    if (COLD) {
+        static_assert(N == 4 || N == 8, "e5_scores: 4 or 8 values at a time");
+        if (N == 8) asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4 % N]), "+v"(sv[5 % N]), "+v"(sv[6 % N]), "+v"(sv[7 % N]));
+        else asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]));
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+            if (a[u] >= hot_bytes) sv[u] = *reinterpret_cast<const double*>(values + a[u]);
+    }
+}
 
 // TGX_STAMPS=1 (diagnostic runs only): s_memtime stamps around the phases of an iteration, summed per wave
 #define E5_STAMP(i)                                                    \
@@ -164,14 +146,14 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
     const uint2* __restrict__ trie = reinterpret_cast<const uint2*>(Q.trie8);
-    // ---- LDS: [0, 8 (n_hot + 1)) score table (entry 0 = -inf) | per-wave pools | root records | match indices
+    // ---- LDS: [0, 8 (n_hot + 1)) score table (entry 0 = -inf: rank 0 = "no token") | root records | match indices
     double* const score_tab = reinterpret_cast<double*>(smem);
-    const uint32_t pool_off = 8u * (Q.n_hot + 1u) + wave * (Q.pool_entries * 8u);  // this wave's pool, byte offset
+    const uint32_t hot_bytes = 8u * (Q.n_hot + 1u);
+    const unsigned char* __restrict__ values = reinterpret_cast<const unsigned char*>(Q.values);
     const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
     unsigned char* wbase = smem + Q.idx_off + (size_t)wave * (PPL * kE5GroupBytes);
     {
-        const double ninf_ = -__builtin_huge_val();
-        for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = i ? Q.hot[i - 1u] : ninf_;
+        for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = Q.values[i];
         uint2* rw = reinterpret_cast<uint2*>(smem + Q.root_off);
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
         __syncthreads();
@@ -179,7 +161,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
 
     uint32_t s = 0, n = 0, p0 = 0;
     uint64_t beg = 0;
-    bool live = false, need_new = true, bad = false;
+    bool live = false, need_new = true;
     const double ninf = -__builtin_huge_val();
     double acc = ninf;
     uint32_t bpv = kNoStep;
@@ -222,7 +204,6 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             acc = (l == 0u) ? 0.0 : ninf;
             bpv = kNoStep;
             pk_dirty = false;
-            bad = false;
         }
         const bool fresh_row = need_new;
         need_new = false;
@@ -274,24 +255,15 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             c[g] = bytes[g][0] & 0xFFu;
             rec[g] = rootc[(Q.root_base ^ c[g]) & 255u];
         }
-        uint32_t pool_cnt = 0;          // wave-uniform: pool entries handed out in this iteration
         {
             // (opaque per trip: as a loop invariant the sixteen column offsets of a lane get hoisted out of the
             // sample loop, kept in registers and spilled)
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
-            WalkCtx<PPL> W{trie, rootc, smem, Q.cold_scores, Q.root_base, Q.pool_entries, pool_off, s, P.flags, l32, P.dropout, P.seed};
-            Walk5<DROPOUT, COLD, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pool_cnt);
+            WalkCtx<PPL> W{trie, smem, s, l32, P.dropout, P.seed};
+            Walk5<DROPOUT, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
         }
         __builtin_amdgcn_wave_barrier();
-        if (COLD) {
-            // the cold matches of this iteration left their slots in the pool: replace them by the scores, all loads
-            // of the batch in flight together (a load issued inside the walk, on some paths only, costs the walks
-            // their stagger: the compiler then waits for every outstanding load at every use)
-            if (pool_cnt > Q.pool_entries) bad = true;  // every row of the wave: their samples share the pool
-            fetch_cold_scores(smem + pool_off, pool_cnt < Q.pool_entries ? pool_cnt : Q.pool_entries, lane, Q.cold_scores);
-            __builtin_amdgcn_wave_barrier();
-        }
         E5_STAMP(2)  // walk
         {   // the following block's text window lands while the relax runs
             const uint32_t* __restrict__ np = wp + 4 * PPL;
@@ -299,7 +271,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             for (int q = 0; q <= 4 * PPL; ++q) wn[q] = np[q];
         }
 
-        // ---- relax: a lane's 16 match indices are 32 contiguous bytes; the scores come from the table
+        // ---- relax: a lane's 16 match indices (ranks) are 32 contiguous bytes; the scores come from the table
         // (the walks — latency chains — issue ahead of the relaxing waves of their SIMD, which fill the gaps:
         // 11.28 -> 11.06 ms; the other way round 11.23 -> 11.53; TGX_FLAGS=32 with TGX_DEBUG=1 switches it off)
         if (!(P.flags & 32u)) __builtin_amdgcn_s_setprio(0);
@@ -316,11 +288,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             // the scores of eight steps at a time (all sixteen cost 32 registers: a wave per SIMD)
             uint32_t fhi = 0xFFF00000u;
             double sv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
-                sv[u] = *reinterpret_cast<const double*>(smem + a);
-            }
+            e5_scores<COLD, 8>(smem, values, iw, 0, hot_bytes, sv);
             relax5_step<0>(sv[0], acc, bpv, fin[g], fhi);
             relax5_step<1>(sv[1], acc, bpv, fin[g], fhi);
             relax5_step<2>(sv[2], acc, bpv, fin[g], fhi);
@@ -329,11 +297,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             relax5_step<5>(sv[5], acc, bpv, fin[g], fhi);
             relax5_step<6>(sv[6], acc, bpv, fin[g], fhi);
             relax5_step<7>(sv[7], acc, bpv, fin[g], fhi);
-#pragma unroll
-            for (int u = 8; u < 16; ++u) {
-                const uint32_t a = (u & 1) ? (iw[u >> 1] >> 16) : (iw[u >> 1] & 0xFFFFu);
-                sv[u - 8] = *reinterpret_cast<const double*>(smem + a);
-            }
+            e5_scores<COLD, 8>(smem, values, iw, 8, hot_bytes, sv);
             relax5_step<8>(sv[0], acc, bpv, fin[g], fhi);
             relax5_step<9>(sv[1], acc, bpv, fin[g], fhi);
             relax5_step<10>(sv[2], acc, bpv, fin[g], fhi);
@@ -372,13 +336,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             if (left < SPAN) {
 #pragma unroll
                 for (int g = 0; g < PPL; ++g)
-                    if (left == 16u * g + l) {
-                        P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
-                        if (COLD && bad) {  // a pool overflow touched this sample: encode4_kernel redoes it
-                            const unsigned long long at = atomicAdd(Q.redo_count, 1ull);
-                            Q.redo_list[at] = s;
-                        }
-                    }
+                    if (left == 16u * g + l) P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
                 need_new = true;
             } else {
                 p0 += SPAN;
@@ -423,7 +381,7 @@ struct E6Ctrl {
     uint32_t s, n, trip0;
     uint64_t beg;
     uint32_t relax_done;
-    uint32_t bad;         // COLD: a walker of the current sample ran out of pool entries (the sample is redone)
+    uint32_t pad_;
     uint32_t walk_done[8];
     uint32_t ack[4];      // walker j -> relaxer: the epoch whose (s, n, beg, trip0) it has read
 };
@@ -432,14 +390,11 @@ constexpr uint32_t kE6Done = 0xFFFFFFFFu;
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// the four score values of a quarter group (steps 4 q .. 4 q + 3) of a lane: 16-bit LDS addresses in iw
-__device__ __forceinline__ void e6_load_quarter(const unsigned char* smem, const uint32_t (&iw)[8], int q, double (&sv)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int v = 4 * q + u;
-        const uint32_t a = (v & 1) ? (iw[v >> 1] >> 16) : (iw[v >> 1] & 0xFFFFu);
-        sv[u] = *reinterpret_cast<const double*>(smem + a);
-    }
+// the four score values of a quarter group (steps 4 q .. 4 q + 3) of a lane: 16-bit ranks in iw
+template <bool COLD>
+__device__ __forceinline__ void e6_load_quarter(const unsigned char* smem, const unsigned char* __restrict__ values, uint32_t hot_bytes,
+                                                const uint32_t (&iw)[8], int q, double (&sv)[4]) {
+    e5_scores<COLD, 4>(smem, values, iw, 4 * q, hot_bytes, sv);
 }
 
 template <bool DROPOUT, bool COLD>
@@ -452,11 +407,12 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint2* __restrict__ trie = reinterpret_cast<const uint2*>(Q.trie8);
     double* const score_tab = reinterpret_cast<double*>(smem);
+    const uint32_t hot_bytes = 8u * (Q.n_hot + 1u);
+    const unsigned char* __restrict__ values = reinterpret_cast<const unsigned char*>(Q.values);
     const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
     E6Ctrl* const ctrl_all = reinterpret_cast<E6Ctrl*>(smem + Q.ctrl_off);
     {
-        const double ninf_ = -__builtin_huge_val();
-        for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = i ? Q.hot[i - 1u] : ninf_;
+        for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = Q.values[i];
         uint2* rw = reinterpret_cast<uint2*>(smem + Q.root_off);
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
         uint32_t* cw = reinterpret_cast<uint32_t*>(ctrl_all);
@@ -542,30 +498,30 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
             uint32_t iwa[8], iwb[8];
             double sva[4], svb[4];
             load_iw(0, iwa);
-            e6_load_quarter(smem, iwa, 0, sva);
+            e6_load_quarter<COLD>(smem, values, hot_bytes, iwa, 0, sva);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint32_t (&iw)[8] = (g & 1) ? iwb : iwa;
                 uint32_t (&iwn)[8] = (g & 1) ? iwa : iwb;
                 fin[g] = kNoStep;
                 uint32_t fhi = 0xFFF00000u;
-                e6_load_quarter(smem, iw, 1, svb);
+                e6_load_quarter<COLD>(smem, values, hot_bytes, iw, 1, svb);
                 if (g < 3) load_iw(g + 1, iwn);
                 relax5_step<0>(sva[0], acc, bpv, fin[g], fhi);
                 relax5_step<1>(sva[1], acc, bpv, fin[g], fhi);
                 relax5_step<2>(sva[2], acc, bpv, fin[g], fhi);
                 relax5_step<3>(sva[3], acc, bpv, fin[g], fhi);
-                e6_load_quarter(smem, iw, 2, sva);
+                e6_load_quarter<COLD>(smem, values, hot_bytes, iw, 2, sva);
                 relax5_step<4>(svb[0], acc, bpv, fin[g], fhi);
                 relax5_step<5>(svb[1], acc, bpv, fin[g], fhi);
                 relax5_step<6>(svb[2], acc, bpv, fin[g], fhi);
                 relax5_step<7>(svb[3], acc, bpv, fin[g], fhi);
-                e6_load_quarter(smem, iw, 3, svb);
+                e6_load_quarter<COLD>(smem, values, hot_bytes, iw, 3, svb);
                 relax5_step<8>(sva[0], acc, bpv, fin[g], fhi);
                 relax5_step<9>(sva[1], acc, bpv, fin[g], fhi);
                 relax5_step<10>(sva[2], acc, bpv, fin[g], fhi);
                 relax5_step<11>(sva[3], acc, bpv, fin[g], fhi);
-                if (g < 3) e6_load_quarter(smem, iwn, 0, sva);
+                if (g < 3) e6_load_quarter<COLD>(smem, values, hot_bytes, iwn, 0, sva);
                 relax5_step<12>(svb[0], acc, bpv, fin[g], fhi);
                 relax5_step<13>(svb[1], acc, bpv, fin[g], fhi);
                 relax5_step<14>(svb[2], acc, bpv, fin[g], fhi);
@@ -603,13 +559,6 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         if (left == 16u * g + l) P.status[s] = (n == 0u || reached[g]) ? 1u : 0u;
-                    if (COLD) {  // every walker of this sample has published its last trip (acquired above)
-                        if (l == 0u && lds_load(&ctrl->bad) != 0u) {
-                            const unsigned long long at = atomicAdd(Q.redo_count, 1ull);
-                            Q.redo_list[at] = s;
-                            lds_store(&ctrl->bad, 0u);
-                        }
-                    }
                     trip0 += n_trips;
                     need_new = true;
                 } else {
@@ -670,17 +619,10 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
             wlane[0] = slot_off + r * kE5RowStride + l * 2u;
             c[0] = bytes[0][0] & 0xFFu;
             rec[0] = rootc[(Q.root_base ^ c[0]) & 255u];
-            uint32_t pool_cnt = 0;
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
-            const uint32_t pool_off = 8u * (Q.n_hot + 1u) + (rw * G + slot) * (Q.pool_entries * 8u);  // the ring slot's pool
-            WalkCtx<1> W{trie, rootc, smem, Q.cold_scores, Q.root_base, Q.pool_entries, pool_off, s, 0u, l32, P.dropout, P.seed};
-            Walk5<DROPOUT, COLD, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c, pool_cnt);
-            if (COLD) {
-                __builtin_amdgcn_wave_barrier();
-                if (pool_cnt > Q.pool_entries && lane == 0u) lds_store(&ctrl->bad, 1u);
-                fetch_cold_scores(smem + pool_off, pool_cnt < Q.pool_entries ? pool_cnt : Q.pool_entries, lane, Q.cold_scores);
-            }
+            WalkCtx<1> W{trie, smem, s, l32, P.dropout, P.seed};
+            Walk5<DROPOUT, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0u) lds_store(&ctrl->walk_done[slot], t + 1u);
         }
@@ -699,16 +641,19 @@ static encode5_fn pick_encode5(bool dropout, bool cold, int ppl) {
     return dropout ? encode5_kernel<true, false, 4> : encode5_kernel<false, false, 4>;
 }
 
-// LDS of one block of `waves` waves: score table + pools (both below 64 KiB: the match indices are 16-bit
-// addresses), root records, match indices.  Returns 0 when the table and pools do not fit below 64 KiB.
-uint32_t encode5_lds_layout(uint32_t n_hot, uint32_t pool_entries, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off) {
-    const uint32_t score_bytes = 8u * (n_hot + 1u) + (uint32_t)waves * pool_entries * 8u;
-    if (score_bytes > 65536u) return 0;
+// LDS of one block of `waves` waves: score table (n_hot + 1 values), root records, match indices
+uint32_t encode5_lds_layout(uint32_t n_hot, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off) {
+    const uint32_t score_bytes = 8u * (n_hot + 1u);
     const uint32_t ro = (score_bytes + 15u) & ~15u;
     const uint32_t io = (ro + 2048u + 511u) & ~511u;  // 512-byte aligned: see kE5RowStride
     if (root_off) *root_off = ro;
     if (idx_off) *idx_off = io;
     return io + (uint32_t)waves * (uint32_t)ppl * kE5GroupBytes;
+}
+// the largest table that leaves a block of `waves` waves within `budget` bytes of LDS
+uint32_t encode5_max_hot(int waves, int ppl, uint32_t budget) {
+    const uint32_t fixed = encode5_lds_layout(0u, waves, ppl, nullptr, nullptr) + 512u;  // alignment slack
+    return budget > fixed + 64u ? (budget - fixed) / 8u : 0u;
 }
 
 hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out) {
@@ -720,11 +665,10 @@ hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out) {
     return hipSuccess;
 }
 
-// LDS of an encode6_kernel block: score table, one pool per ring slot (COLD), root records, control words of
-// the four rows, four rings of kE6Slots match-index buffers
-uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool_entries, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
-    const uint32_t score_bytes = 8u * (n_hot + 1u) + 4u * kE6Slots * pool_entries * 8u;
-    if (score_bytes > 65536u) return 0;
+// LDS of an encode6_kernel block: score table, root records, control words of the four rows, four rings of
+// kE6Slots match-index buffers
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
+    const uint32_t score_bytes = 8u * (n_hot + 1u);
     const uint32_t ro = (score_bytes + 15u) & ~15u;
     const uint32_t co = ro + 2048u;
     const uint32_t go = (co + 4u * (uint32_t)sizeof(E6Ctrl) + 511u) & ~511u;
@@ -733,15 +677,14 @@ uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool_entries, uint32_t* roo
     if (ring_off) *ring_off = go;
     return go + 4u * kE6Slots * kE5GroupBytes;
 }
-uint32_t encode6_max_pool_entries(uint32_t n_hot) {
-    const uint32_t room = 65536u - 8u * (n_hot + 1u);
-    return std::min<uint32_t>(256u, room / (8u * 4u * kE6Slots)) & ~3u;
+uint32_t encode6_max_hot(uint32_t budget) {
+    const uint32_t fixed = encode6_lds_layout(0u, nullptr, nullptr, nullptr) + 512u;
+    return budget > fixed + 64u ? (budget - fixed) / 8u : 0u;
 }
 hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream) {
     q.ring_slots = kE6Slots;
-    if (!cold) q.pool_entries = 0u;
-    const uint32_t lds = encode6_lds_layout(q.n_hot, q.pool_entries, &q.root_off, &q.ctrl_off, &q.ring_off);
-    if (lds == 0 || lds > 160u * 1024u) return hipErrorInvalidValue;
+    const uint32_t lds = encode6_lds_layout(q.n_hot, &q.root_off, &q.ctrl_off, &q.ring_off);
+    if (lds > 160u * 1024u || q.n_hot > q.n_values) return hipErrorInvalidValue;
     auto fn = cold ? (p.dropout > 0.0 ? encode6_kernel<true, true> : encode6_kernel<false, true>)
                    : (p.dropout > 0.0 ? encode6_kernel<true, false> : encode6_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -751,8 +694,8 @@ hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uin
 }
 
 hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
-    const uint32_t lds = encode5_lds_layout(q.n_hot, q.pool_entries, waves, ppl, &q.root_off, &q.idx_off);
-    if (lds == 0 || lds > 160u * 1024u) return hipErrorInvalidValue;
+    const uint32_t lds = encode5_lds_layout(q.n_hot, waves, ppl, &q.root_off, &q.idx_off);
+    if (lds > 160u * 1024u || q.n_hot > q.n_values || (!cold && q.n_hot != q.n_values)) return hipErrorInvalidValue;
     encode5_fn fn = pick_encode5(p.dropout > 0.0, cold, ppl);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;

@@ -127,12 +127,15 @@ __global__ __launch_bounds__(256) void run_heads_kernel(const uint64_t* __restri
 }
 
 // rep[run] = the run's first entry; df[run] += 1 for every entry that opens a new sample inside its run.
-// (Straight-line on purpose: written with short-circuit loads of entry i - 1, hipcc 7.2 kept the run index in a
-// register pair that the merged 16-byte load of keys[i - 1 .. i] overwrites on one path, and the atomic went
-// to a wild address.)
+// A run id outside [1, n_runs] cannot come out of an inclusive scan of the heads; it is never used as an index,
+// and it is COUNTED (bad_runs): the host fails the call with TGX_ERR_DEVICE instead of returning frequencies with
+// entries missing.  (Round 2 met a wild atomic address in an earlier, short-circuit form of this kernel whose
+// source was not kept; the reconstructions under profiles/r03/run_count_short_circuit.* do not show a compiler
+// defect, so the cause of that fault is NOT established — hence the loud guard.)
 __global__ __launch_bounds__(256) void run_count_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ run_id, uint64_t n, uint32_t n_runs,
-                                                        uint64_t* __restrict__ rep, uint32_t* __restrict__ df) {
+                                                        uint64_t* __restrict__ rep, uint32_t* __restrict__ df,
+                                                        unsigned long long* __restrict__ bad_runs) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const uint64_t j = i ? i - 1 : 0;
@@ -140,7 +143,10 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint64_t* __restri
     const uint32_t r = run_id[i] - 1u;
     const bool head = (i == 0) | (k != kp);
     const bool newdoc = head | ((v >> 37) != (vp >> 37));
-    if (r >= n_runs) return;  // cannot happen (run ids are an inclusive scan of the heads); never index with it
+    if (r >= n_runs) {
+        atomicAdd(bad_runs, 1ull);
+        return;
+    }
     if (head) rep[r] = v;
     if (newdoc) atomicAdd(&df[r], 1u);
 }
@@ -148,10 +154,14 @@ __global__ __launch_bounds__(256) void run_count_kernel(const uint64_t* __restri
 // every entry's window against its run's representative, byte by byte
 __global__ __launch_bounds__(256) void run_check_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ vals,
                                                         const uint32_t* __restrict__ run_id, uint64_t n, uint32_t n_runs,
-                                                        const uint64_t* __restrict__ rep, unsigned long long* __restrict__ collisions) {
+                                                        const uint64_t* __restrict__ rep, unsigned long long* __restrict__ collisions,
+                                                        unsigned long long* __restrict__ bad_runs) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    if (run_id[i] - 1u >= n_runs) return;
+    if (run_id[i] - 1u >= n_runs) {
+        atomicAdd(bad_runs, 1ull);
+        return;
+    }
     const uint64_t a = vals[i], b = rep[run_id[i] - 1u];
     if (a == b) return;
     const uint32_t la = (uint32_t)(a & 31u) + 1u, lb = (uint32_t)(b & 31u) + 1u;
@@ -318,19 +328,20 @@ tgx_status tgx_substring_df(int device, const uint8_t* text, uint64_t n_bytes, c
         for (uint64_t i = 0; i < std::min<uint64_t>(M, 24); i++) fprintf(stderr, " %u/%u", hh[i], hh[M + i]);
         fprintf(stderr, "\n[tgx] generate: d_keys=%p d_vals=%p d_keys2=%p d_vals2=%p d_head=%p d_run=%p\n", (void*)d_keys, (void*)d_vals,
                 (void*)d_keys2, (void*)d_vals2, (void*)d_head, (void*)d_run);
-        if (getenv("TGX_DEBUG")[0] == '2') return fail(TGX_ERR_DEVICE, "debug stop before run_count_kernel");
     }
     if (n_runs == 0 || n_runs > M) return fail(TGX_ERR_DEVICE, "tgx_substring_df: inconsistent run count");
     uint64_t* d_rep = d_vals;  // the unsorted values are free now: n_runs <= M
     uint32_t* d_df = (uint32_t*)dalloc((size_t)n_runs * 4);
     if (!d_df) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
     G_TRY(hipMemset(d_df, 0, (size_t)n_runs * 4));
-    hipLaunchKernelGGL(run_count_kernel, dim3(mblocks), dim3(256), 0, 0, d_keys2, d_vals2, d_run, M, n_runs, d_rep, d_df);
+    hipLaunchKernelGGL(run_count_kernel, dim3(mblocks), dim3(256), 0, 0, d_keys2, d_vals2, d_run, M, n_runs, d_rep, d_df, d_ctr + 1);
     G_TRY(hipGetLastError());
-    hipLaunchKernelGGL(run_check_kernel, dim3(mblocks), dim3(256), 0, 0, d_text, d_vals2, d_run, M, n_runs, d_rep, d_ctr);
+    hipLaunchKernelGGL(run_check_kernel, dim3(mblocks), dim3(256), 0, 0, d_text, d_vals2, d_run, M, n_runs, d_rep, d_ctr, d_ctr + 1);
     G_TRY(hipGetLastError());
-    unsigned long long coll = 0;
-    G_TRY(hipMemcpy(&coll, d_ctr, 8, hipMemcpyDeviceToHost));
+    unsigned long long ctr[2] = {0, 0};  // [0] hash collisions, [1] entries whose run id was out of range
+    G_TRY(hipMemcpy(ctr, d_ctr, 16, hipMemcpyDeviceToHost));
+    if (ctr[1]) return fail(TGX_ERR_DEVICE, "tgx_substring_df: entries with a run id outside [1, n_runs] (run ids corrupt)");
+    const unsigned long long coll = ctr[0];
     if (n_collisions) *n_collisions = coll;
     if (coll) return fail(TGX_ERR_UNSUPPORTED, "tgx_substring_df: two different substrings share a 64-bit hash: use the host path for this batch");
     std::vector<uint64_t> rep(n_runs);

@@ -33,18 +33,16 @@ struct EncodeParams {
     unsigned long long* stamps;     // diagnostic build only (TGX_STAMPS=1): 8 u64 per wave
 };
 
-// encode5_kernel (encode5.hip): 8-byte label-checked records, score values in an LDS table
+// encode5_kernel / encode6_kernel (encode5.hip): 8-byte label-checked records, score values by rank
 struct Encode5Params {
     const void* trie8;              // Trie8Rec[n_slots]
-    const double* cold_scores;      // f64[n_slots]: score of every terminal slot (values outside the table)
-    const double* hot;              // f64[n_hot]: the table's values, entry i at LDS byte offset 8 (i + 1)
-    uint32_t root_base, n_hot;
-    uint32_t pool_entries;          // per wave: LDS entries for cold values of one iteration
+    const double* values;           // f64[n_values + 1]: values[0] = -inf, values[r] = the score value of rank r
+    uint32_t root_base;
+    uint32_t n_values;              // distinct score values of the vocabulary (<= 65 535)
+    uint32_t n_hot;                 // ranks 1..n_hot are copied into the block's LDS; COLD builds read the rest from `values`
     uint32_t claim_chunk;           // consecutive samples of the order a row claims per atomic (>= 1)
     uint32_t root_off, idx_off;     // LDS layout (set by the launcher)
     uint32_t ctrl_off, ring_off, ring_slots;  // encode6_kernel: control words, ring of match-index buffers
-    unsigned long long* redo_count; // samples whose wave ran out of pool entries (init 0) ...
-    uint32_t* redo_list;            // ... and their indices, u32[S]: encode4_kernel redoes exactly those
 };
 
 struct CompactParams {
@@ -151,10 +149,11 @@ hipError_t encode4_waves_per_simd(bool dropout, int ppl, bool root, int* out);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream);
 uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
-uint32_t encode5_lds_layout(uint32_t n_hot, uint32_t pool_entries, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off);
+uint32_t encode5_lds_layout(uint32_t n_hot, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off);
+uint32_t encode5_max_hot(int waves, int ppl, uint32_t budget);
 hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out);
-uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool_entries, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
-uint32_t encode6_max_pool_entries(uint32_t n_hot);
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
+uint32_t encode6_max_hot(uint32_t budget);
 hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip

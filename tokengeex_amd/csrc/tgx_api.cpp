@@ -167,11 +167,10 @@ struct KernelTime {
     bool used;
 };
 constexpr int kMaxTimed = 8;
-// encode5_kernel: values in the LDS score table (the table and the per-wave pools of cold values share the
-// 64 KiB a 16-bit match index can address) and pool entries per wave
-constexpr uint32_t kE5MaxHot = 6600;      // score values in the LDS table when all of a vocabulary's values fit
-constexpr uint32_t kE5MaxHotCold = 4095;  // ... when they do not: 32 KiB of table, 32 KiB of 16-bit addresses for the pools
-constexpr uint32_t kE5PoolWanted = 192;   // entries per wave and iteration that the geometry is chosen for
+// encode5_kernel with a vocabulary whose score values do not all fit the block's LDS beside sixteen waves of
+// match indices (COLD builds): waves per block, which fixes the size of the LDS copy of the value table
+// (encode5_max_hot: 14 waves leave room for ~5 700 values, 12 for ~7 800, 16 for ~3 700)
+constexpr int kE5ColdWaves = 14;
 
 }  // namespace
 
@@ -205,13 +204,13 @@ struct tgx_model {
     void* d_tokhash = nullptr;
     // encode5_kernel: 8-byte label-checked records + table of distinct score values (trie_build.h: Trie8)
     void* d_trie8 = nullptr;
-    double* d_cold_scores = nullptr;
-    double* d_hot = nullptr;
-    uint32_t n_hot = 0, root_base8 = 0;
-    bool have_trie8 = false, has_cold = false;
+    double* d_values = nullptr;        // f64[n_values + 1]: -inf, then the distinct score values by rank (trie_build.h: Trie8)
+    std::vector<double> value_coverage;  // [k]: expected share of the matches whose value has rank <= k
+    uint32_t n_values = 0, root_base8 = 0;
+    uint32_t last_n_hot = 0;           // values in the LDS copy of the last encode5 launch
+    bool have_trie8 = false;
     bool encode_tables_ready = false;  // tokhash / trie8 built and uploaded (ensure_encode_tables)
     bool tokhash_host_built = false;   // m->tokhash was built beside the forward trie at creation
-    double hot_coverage = 0.0;
     int estep_blocks_per_cu = 0;
     KernelTime timed[kMaxTimed] = {};
     int n_timed = 0;
@@ -281,6 +280,18 @@ bool debug_on() {
         v = (e && *e && *e != '0') ? 1 : 0;
     }
     return v == 1;
+}
+
+// Environment switches that choose among the library's (all correct) kernels and geometries exist for the
+// parity tests, A/B timing and diagnosis; a process must opt in with TGX_KNOBS=1 (tests/conftest.py does) or
+// TGX_DEBUG=1, so that a stray variable in a production environment changes nothing.
+const char* knob(const char* name) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("TGX_KNOBS");
+        on = ((e && *e && *e != '0') || debug_on()) ? 1 : 0;
+    }
+    return on == 1 ? getenv(name) : nullptr;
 }
 
 void time_begin(tgx_model* m, const char* name) {
@@ -358,72 +369,66 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         p.flags = f ? (uint32_t)atoi(f) : 0u;
     }
     // TGX_PATH=fused forces the one-sample-per-wave kernel (A/B timing, tests of both paths)
-    const char* force = getenv("TGX_PATH");
+    const char* force = knob("TGX_PATH");
     const bool use4 = m->lm <= 16 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
     // vocabularies with tokens of 17..32 bytes (after `merge`): two samples per wave (encode2.hip)
     const bool use2 = !use4 && m->lm <= 32 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
-    if (debug_on())
-        fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u\n",
-                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? (m->have_trie8 && !m->has_cold ? "rows5" : "rows4") : (use2 ? "rows2" : "fused"),
-                m->flat.table.size(), p.root_base);
-    // encode5_kernel (8-byte records, score values in LDS) for vocabularies whose distinct score values all fit
-    // its table (generate-style vocabularies: scores are logs of integer counts).  A vocabulary with more values
-    // than that (after an M-step every token has its own) stays on encode4_kernel: the pools that would serve
-    // its cold values (a third of the matches at 32 000 entries) cost what the 16-byte records cost, and every
-    // overflow sends a sample to a second pass (profiles/r02: w_cold_vocabulary_*).  TGX_PATH=rows4 / rows5 force either
+    // encode5_kernel / encode6_kernel (8-byte records with child masks, match indices = ranks of score values, the
+    // hottest values in LDS and the rest read from L2 by the relaxing lane) for every vocabulary of tokens <= 16 bytes
+    // with finite scores and at most 65 535 distinct score values — round 3: that includes vocabularies in which
+    // every token has its own score (after an M-step or merge: any trained vocabulary).  encode4_kernel remains for
+    // more distinct values than that (the 500 000-entry stages of prune).  TGX_PATH=rows4 / rows5 force either
     // kernel (A/B timing, tests of both paths).
-    const bool use5 = use4 && m->have_trie8 && !(force && strcmp(force, "rows4") == 0) &&
-                      (!m->has_cold || (force && strcmp(force, "rows5") == 0));
+    const bool use5 = use4 && m->have_trie8 && !(force && strcmp(force, "rows4") == 0);
+    if (debug_on())
+        fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u values=%u\n",
+                (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? (use5 ? "rows5" : "rows4") : (use2 ? "rows2" : "fused"),
+                m->flat.table.size(), p.root_base, m->n_values);
     if (use5) {
         // Four positions per lane and iteration: the four walks of a lane are staggered (encode5.hip: Walk5), so
         // more of them hide more of each other's gather latency, and four was the fastest on every corpus shape
         // measured (profiles/r02: 1 GiB of samples <= 64 KiB / 4 KiB / 1 KiB, 256 MiB of samples <= 256 B, and the
-        // serial chain of a single 64 KiB sample).  One block of sixteen waves per CU (78 registers: six waves
-        // per SIMD would fit, the 8 KiB of match indices per wave do not); fewer waves when the score table is
-        // large, and when the batch has fewer samples than the chip has rows, so that they spread over the CUs.
+        // serial chain of a single 64 KiB sample).  One block of sixteen waves per CU (87 registers: five waves
+        // per SIMD would fit, the 8 KiB of match indices per wave do not).  The block's LDS holds a copy of the
+        // first n_hot score values: all of them when they fit beside sixteen waves (no COLD code in the kernel),
+        // otherwise what kE5ColdWaves waves leave room for; fewer waves when the batch has fewer samples than
+        // the chip has rows, so that they spread over the CUs.
         int ppl = 4;
-        if (const char* e = getenv("TGX_PPL")) {
+        if (const char* e = knob("TGX_PPL")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) ppl = v;
         }
+        int bpc = ppl == 4 ? 1 : 2;
+        if (const char* e = knob("TGX_BPC")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8) bpc = v;
+        }
+        const uint32_t budget = 160u * 1024u / (uint32_t)bpc;
+        bool cold = false;
         int per_simd = 0;
-        HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, m->has_cold, ppl, &per_simd));
-        int bpc = ppl == 4 ? 1 : 2, waves = std::min(16, (per_simd / bpc) * 4);
+        HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, ppl, &per_simd));
+        int waves = std::min(16, (per_simd / bpc) * 4);
+        if (m->n_values > tgx::encode5_max_hot(waves, ppl, budget)) {
+            cold = true;
+            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, true, ppl, &per_simd));
+            waves = std::min(std::min(16, (per_simd / bpc) * 4), ppl == 4 ? kE5ColdWaves : 16);
+        }
         {
             const uint64_t rows_wanted = (c->n_samples + (uint64_t)m->num_cus * bpc - 1) / ((uint64_t)m->num_cus * bpc);
             waves = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)waves, (rows_wanted + 3) / 4));
         }
-        if (const char* e = getenv("TGX_WAVES")) {
+        if (const char* e = knob("TGX_WAVES")) {
             const int v = atoi(e);
             if (v >= 1 && v <= 16) waves = v;
         }
-        if (const char* e = getenv("TGX_BPC")) {
+        while (waves > 1 && tgx::encode5_max_hot(waves, ppl, budget) < 16u) waves--;
+        uint32_t n_hot = std::min(m->n_values, tgx::encode5_max_hot(waves, ppl, budget));
+        if (const char* e = knob("TGX_E5_HOT")) {  // tests of the COLD builds (a small LDS copy), table-size sweeps
             const int v = atoi(e);
-            if (v >= 1 && v <= 8) bpc = v;
+            if (v >= 0) n_hot = std::min(n_hot, (uint32_t)v);
         }
-        // Cold-value pool of a wave (vocabularies whose score values do not all fit the table): one entry per cold
-        // match of an iteration (64 lanes x ppl start positions).  A wave that runs out sends its four samples to
-        // the redo pass, and a 64 KiB sample lives through a thousand iterations, so the pool is made as large as
-        // the 16-bit address space of the match indices (table + pools < 64 KiB) and the block's LDS allow.
-        uint32_t pool = 0;
-        if (m->has_cold) {
-            uint32_t want = kE5PoolWanted;  // fewer waves rather than a pool below this
-            if (const char* e = getenv("TGX_E5_POOL")) want = (uint32_t)std::min(2048, std::max(4, atoi(e)));
-            const uint32_t room16 = 65536u - 8u * (m->n_hot + 1u);
-            for (;; waves--) {
-                const uint32_t fixed = tgx::encode5_lds_layout(m->n_hot, 0u, waves, ppl, nullptr, nullptr);  // table, root, indices
-                const uint32_t budget = 160u * 1024u / (uint32_t)bpc;
-                const uint32_t room = fixed && fixed + 1024u < budget ? std::min(room16, budget - fixed - 1024u) : 0u;
-                pool = std::min<uint32_t>(1024u, room / (8u * (uint32_t)waves)) & ~3u;
-                if (pool >= want || waves == 1) break;
-            }
-            if (pool > want && getenv("TGX_E5_POOL")) pool = want;  // experiments: exactly the size asked for
-        }
-        while (waves > 1) {
-            const uint32_t lds = tgx::encode5_lds_layout(m->n_hot, pool, waves, ppl, nullptr, nullptr);
-            if (lds != 0 && lds * (uint32_t)bpc <= 160u * 1024u) break;
-            waves--;
-        }
+        cold = n_hot < m->n_values;
+        m->last_n_hot = n_hot;
         // whole blocks only: a block's waves are dealt round-robin to the SIMDs, ceil(waves / 4) on the fullest
         m->last_encode_waves_per_cu = std::min(bpc, per_simd / ((waves + 3) / 4)) * waves;
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
@@ -431,34 +436,39 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
         tgx::Encode5Params q{};
         q.trie8 = m->d_trie8;
-        q.cold_scores = m->d_cold_scores;
-        q.hot = m->d_hot;
+        q.values = m->d_values;
         q.root_base = m->root_base8;
-        q.n_hot = m->n_hot;
-        q.pool_entries = pool;  // no pools for a vocabulary whose values all fit the table
-        q.redo_count = m->d_ctrl + 6;
-        q.redo_list = c->d_counts;  // free until the trace writes the token counts
+        q.n_values = m->n_values;
+        q.n_hot = n_hot;
         {   // rows claim several consecutive samples of the order per atomic when samples are short: one global
             // atomic round trip (~1-2 us) per sample is what a corpus of 130-byte samples otherwise waits for
             const uint64_t avg = c->n_samples ? c->n_bytes / c->n_samples : 0;
             q.claim_chunk = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, 4096 / std::max<uint64_t>(1, avg)));
-            if (const char* e = getenv("TGX_CLAIM_CHUNK")) q.claim_chunk = (uint32_t)std::min(64, std::max(1, atoi(e)));
+            if (const char* e = knob("TGX_CLAIM_CHUNK")) q.claim_chunk = (uint32_t)std::min(64, std::max(1, atoi(e)));
         }
         m->last_redo_samples = 0;
-        if (m->has_cold) HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
         // Long samples first, four to a block (encode6_kernel: three walker waves per sample ahead of one row of the
         // block's relaxing wave), when that shortens the pass.  encode5_kernel takes ~0.104 us per byte of a
         // sample's serial chain (6.8 ms per 64 KiB) and ~1 s per 88 GB of batch; encode6_kernel ~0.037 us per byte
         // of chain (2.4 ms per 64 KiB) but ~55 GB/s once every CU has its two blocks (eight relaxing rows per CU;
         // profiles/r02: e6 shapes).  The two run one after the other, so the split is chosen among the powers of
         // two as thresholds by the sum of the two estimates; TGX_LONG_THRESHOLD forces one (0: never).
+        // Its LDS copy of the value table is what two blocks per CU leave room for (~4 500 values).
+        int e6_bpc = 2;
+        if (const char* e = knob("TGX_E6_BPC")) e6_bpc = std::min(4, std::max(1, atoi(e)));
+        uint32_t n_hot6 = std::min(m->n_values, tgx::encode6_max_hot(160u * 1024u / (uint32_t)e6_bpc));
+        if (const char* e = knob("TGX_E5_HOT")) {
+            const int v = atoi(e);
+            if (v >= 0) n_hot6 = std::min(n_hot6, (uint32_t)v);
+        }
+        const bool cold6 = n_hot6 < m->n_values;
         uint64_t n_long = 0;
         if (c->n_samples) {
             const auto count_ge = [&](uint64_t thr) {  // h_sorted_len descends: the long samples are a prefix of the order
                 return (uint64_t)(std::partition_point(c->h_sorted_len.begin(), c->h_sorted_len.end(),
                                                        [thr](uint32_t len) { return len >= thr; }) - c->h_sorted_len.begin());
             };
-            if (const char* e = getenv("TGX_LONG_THRESHOLD")) {
+            if (const char* e = knob("TGX_LONG_THRESHOLD")) {
                 const uint64_t thr = (uint64_t)std::max(0ll, atoll(e));
                 if (thr) n_long = count_ge(thr);
             } else {
@@ -485,17 +495,12 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         if (n_long) {
             tgx::EncodeParams p6 = p;
             p6.n_samples = n_long;
-            // four samples per block (one per row of its relaxing wave); 13 waves of 69 registers, 60 KiB of LDS: two blocks per CU
-            int e6_bpc = 2;
-            if (const char* e = getenv("TGX_E6_BPC")) e6_bpc = std::min(4, std::max(1, atoi(e)));
+            // four samples per block (one per row of its relaxing wave); 13 waves of 64 registers: two blocks per CU
             const uint32_t blocks6 = (uint32_t)std::min<uint64_t>((n_long + 3) / 4, (uint64_t)m->num_cus * (uint64_t)e6_bpc);
             time_begin(m, "encode6_kernel");
-            tgx::Encode5Params q6 = q;  // one pool per ring slot (64 positions)
-            if (m->has_cold) {
-                q6.pool_entries = tgx::encode6_max_pool_entries(m->n_hot);
-                if (const char* e = getenv("TGX_E5_POOL")) q6.pool_entries = std::min<uint32_t>(q6.pool_entries, (uint32_t)std::max(4, atoi(e)));
-            }
-            HIP_TRY(tgx::launch_encode6(p6, q6, m->has_cold, blocks6, m->stream));
+            tgx::Encode5Params q6 = q;
+            q6.n_hot = n_hot6;
+            HIP_TRY(tgx::launch_encode6(p6, q6, cold6, blocks6, m->stream));
             time_end(m);
             HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode5_kernel
             p.order = c->d_order + n_long;
@@ -503,20 +508,35 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         unsigned long long* d_stamps5 = nullptr;
         const size_t n_stamp_waves5 = (size_t)blocks5 * (size_t)waves;
-        if (const char* e = getenv("TGX_STAMPS")) {
+        if (const char* e = debug_on() ? getenv("TGX_STAMPS") : nullptr) {
             if (*e == '1') {
-                HIP_TRY(hipMalloc((void**)&d_stamps5, n_stamp_waves5 * 64));
-                HIP_TRY(hipMemsetAsync(d_stamps5, 0, n_stamp_waves5 * 64, m->stream));
+                if (pool_alloc(m->device, n_stamp_waves5 * 64, (void**)&d_stamps5) != hipSuccess) return fail(TGX_ERR_DEVICE, "out of device memory (stamps)");
+                if (hipMemsetAsync(d_stamps5, 0, n_stamp_waves5 * 64, m->stream) != hipSuccess) {
+                    pool_free(m->device, d_stamps5, n_stamp_waves5 * 64);
+                    return fail(TGX_ERR_DEVICE, "stamps reset failed");
+                }
                 p.stamps = d_stamps5;
             }
         }
         time_begin(m, "encode5_kernel");
-        HIP_TRY(tgx::launch_encode5(p, q, m->has_cold, ppl, waves, blocks5, m->stream));
+        {
+            const hipError_t le = tgx::launch_encode5(p, q, cold, ppl, waves, blocks5, m->stream);
+            if (le != hipSuccess) {
+                if (d_stamps5) {
+                    (void)hipStreamSynchronize(m->stream);
+                    pool_free(m->device, d_stamps5, n_stamp_waves5 * 64);
+                }
+                return fail(TGX_ERR_DEVICE, "encode5 launch failed: %s", hipGetErrorString(le));
+            }
+        }
         time_end(m);
         if (d_stamps5) {  // diagnostic: mean ticks per iteration and phase over all waves
             std::vector<unsigned long long> h(n_stamp_waves5 * 8);
-            HIP_TRY(hipStreamSynchronize(m->stream));
-            HIP_TRY(hipMemcpy(h.data(), d_stamps5, n_stamp_waves5 * 64, hipMemcpyDeviceToHost));
+            const bool ok = hipStreamSynchronize(m->stream) == hipSuccess &&
+                            hipMemcpy(h.data(), d_stamps5, n_stamp_waves5 * 64, hipMemcpyDeviceToHost) == hipSuccess;
+            pool_free(m->device, d_stamps5, n_stamp_waves5 * 64);
+            p.stamps = nullptr;
+            if (!ok) return fail(TGX_ERR_DEVICE, "stamps copy failed");
             double sum[5] = {0, 0, 0, 0, 0}, iters = 0;
             for (size_t w = 0; w < n_stamp_waves5; w++) {
                 for (int i = 0; i < 5; i++) sum[i] += (double)h[w * 8 + i];
@@ -524,30 +544,6 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             }
             fprintf(stderr, "[tgx] encode5 stamps (s_memtime ticks per wave-iteration, %zu waves x ppl %d, %.0f iterations): switch %.0f  text+reset %.0f  walk %.0f  relax %.0f  store %.0f\n",
                     n_stamp_waves5, ppl, iters, sum[0] / iters, sum[1] / iters, sum[2] / iters, sum[3] / iters, sum[4] / iters);
-            (void)hipFree(d_stamps5);
-            p.stamps = nullptr;
-        }
-        if (m->has_cold) {  // only a vocabulary with values outside the table can run a wave out of pool entries
-            unsigned long long n_redo = 0;
-            HIP_TRY(hipMemcpyAsync(&n_redo, m->d_ctrl + 6, 8, hipMemcpyDeviceToHost, m->stream));
-            HIP_TRY(hipStreamSynchronize(m->stream));
-            if (n_redo > c->n_samples) return fail(TGX_ERR_DEVICE, "redo list longer than the batch");
-            m->last_redo_samples = n_redo;
-            if (n_redo) {
-                tgx::EncodeParams r4 = p;
-                r4.order = c->d_counts;
-                r4.n_samples = n_redo;
-                HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
-                // few samples: their serial chains are the cost (four positions per lane: 9.1 ms per 64 KiB against
-                // 13.5); many: throughput (one position per lane, ten waves per block)
-                const bool few = n_redo <= (uint64_t)m->num_cus * 20;
-                const int ppl4 = few ? 4 : 1, waves4 = few ? 5 : 10;
-                const uint64_t rows4 = 4 * (uint64_t)waves4;
-                const uint32_t b4 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_redo + rows4 - 1) / rows4, (uint64_t)m->num_cus * (few ? 1 : 2)));
-                time_begin(m, "encode4_kernel");
-                HIP_TRY(tgx::launch_encode4(r4, ppl4, waves4, b4, !few, m->stream));
-                time_end(m);
-            }
         }
         p.order = c->d_order;
         p.n_samples = c->n_samples;
@@ -557,8 +553,10 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         HIP_TRY(tgx::launch_trace(p, blocks_t, m->stream));
         time_end(m);
     } else if (use4) {
+        // Vocabularies without 8-byte records (more than 65 535 distinct score values): round 1's kernel over the
+        // 16-byte records, scores through the match buffer.
         // `bpc` blocks per CU of `waves` waves each (8 KiB of LDS per wave and position group).
-        // TGX_PPL (positions per lane: 1, 2, 4), TGX_WAVES, TGX_BPC override the defaults.
+        // TGX_PPL (positions per lane: 1, 2, 4), TGX_WAVES, TGX_BPC override the defaults (with TGX_DEBUG=1).
         // Two blocks of ten waves per CU (20 x 8 KiB of LDS); rows claim samples dynamically, so the
         // geometry only has to fill the CU.
         int ppl = 1, waves = 10, bpc = 2;
@@ -580,94 +578,25 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             if (ppl_out) *ppl_out = best_ppl;
             return best_t;
         };
-        // The longest samples to encode6_kernel (its build with cold-value pools: this branch is where models with
-        // more score values than the LDS table holds end up) when the estimate says the pass gets shorter — the
-        // same choice among powers of two as above, against encode4_kernel's constants.  A sample whose ring slot
-        // ran out of pool entries comes back on the redo list and is encoded below with the rest.
-        uint64_t n_long4 = 0;
-        if (m->have_trie8 && c->n_samples && !(force && strcmp(force, "rows4") == 0 && !getenv("TGX_LONG_THRESHOLD")) &&
-            tgx::encode6_max_pool_entries(m->n_hot) >= 32u) {
-            const auto count_ge = [&](uint64_t thr) {
-                return (uint64_t)(std::partition_point(c->h_sorted_len.begin(), c->h_sorted_len.end(),
-                                                       [thr](uint32_t len) { return len >= thr; }) - c->h_sorted_len.begin());
-            };
-            if (const char* e = getenv("TGX_LONG_THRESHOLD")) {
-                const uint64_t thr = (uint64_t)std::max(0ll, atoll(e));
-                if (thr) n_long4 = count_ge(thr);
-            } else {
-                const double N = (double)c->n_bytes;
-                auto cost = [&](uint64_t k) {
-                    const double bytes_long = k ? (double)c->h_sorted_cum[k - 1] : 0.0;
-                    // (with pools: 32 KiB of table + 32 KiB of pools leave room for ONE block per CU: ~20 GB/s measured)
-                    const double t6 = k ? std::max((double)c->h_sorted_len[0] * 0.0369e-6, bytes_long / (m->has_cold ? 20e9 : 55e9)) + 40e-6 : 0.0;
-                    const double rest_max = k < c->n_samples ? (double)c->h_sorted_len[k] : 0.0;
-                    return t6 + cost4(N - bytes_long, rest_max, nullptr);
-                };
-                double best = cost(0);
-                for (uint64_t thr = 1024; thr <= c->max_len; thr *= 2) {
-                    const uint64_t k = count_ge(thr);
-                    const double ck = cost(k);
-                    if (k && ck < best * 0.9) {
-                        best = ck;
-                        n_long4 = k;
-                    }
-                }
-            }
-        }
-        m->last_long_samples = n_long4;
+        m->last_long_samples = 0;
         m->last_redo_samples = 0;
-        uint64_t n_redo4 = 0;
-        if (n_long4) {
-            tgx::Encode5Params q{};
-            q.trie8 = m->d_trie8;
-            q.cold_scores = m->d_cold_scores;
-            q.hot = m->d_hot;
-            q.root_base = m->root_base8;
-            q.n_hot = m->n_hot;
-            q.pool_entries = m->has_cold ? tgx::encode6_max_pool_entries(m->n_hot) : 0u;
-            if (const char* e = getenv("TGX_E5_POOL")) q.pool_entries = std::min<uint32_t>(q.pool_entries, (uint32_t)std::max(4, atoi(e)));
-            q.redo_count = m->d_ctrl + 6;
-            q.redo_list = c->d_counts;  // free until the trace writes the token counts
-            HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
-            tgx::EncodeParams p6 = p;
-            p6.n_samples = n_long4;
-            const uint32_t blocks6 = (uint32_t)std::min<uint64_t>((n_long4 + 3) / 4, (uint64_t)m->num_cus * 2);
-            time_begin(m, "encode6_kernel");
-            HIP_TRY(tgx::launch_encode6(p6, q, m->has_cold, blocks6, m->stream));
-            time_end(m);
-            if (m->has_cold) {
-                unsigned long long nr = 0;
-                HIP_TRY(hipMemcpyAsync(&nr, m->d_ctrl + 6, 8, hipMemcpyDeviceToHost, m->stream));
-                HIP_TRY(hipStreamSynchronize(m->stream));
-                if (nr > n_long4) return fail(TGX_ERR_DEVICE, "redo list longer than the batch");
-                n_redo4 = nr;
-                m->last_redo_samples = nr;
-            }
-            HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode4_kernel
-            p.order = c->d_order + n_long4;
-            p.n_samples = c->n_samples - n_long4;
-        }
-        {
-            const double rest_bytes = (double)c->n_bytes - (n_long4 ? (double)c->h_sorted_cum[n_long4 - 1] : 0.0);
-            const double rest_max = n_long4 < c->n_samples ? (double)c->h_sorted_len[n_long4] : 0.0;
-            cost4(rest_bytes, rest_max, &ppl);
-        }
-        if (const char* e = getenv("TGX_PPL")) {
+        cost4((double)c->n_bytes, c->n_samples ? (double)c->h_sorted_len[0] : 0.0, &ppl);
+        if (const char* e = knob("TGX_PPL")) {  // (also set by tests: every positions-per-lane build against the oracle)
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) ppl = v;
         }
         if (ppl == 2) { waves = 5; bpc = 2; }
         if (ppl == 4) { waves = 5; bpc = 1; }
-        if (const char* e = getenv("TGX_WAVES")) {
+        if (const char* e = knob("TGX_WAVES")) {
             const int v = atoi(e);
             if (v >= 1 && v <= 16) waves = v;
         }
-        if (const char* e = getenv("TGX_BPC")) {
+        if (const char* e = knob("TGX_BPC")) {
             const int v = atoi(e);
             if (v >= 1 && v <= 8) bpc = v;
         }
         bool root = ppl == 1;  // first trie level in LDS (4 KiB per block)
-        if (const char* e = getenv("TGX_ROOT")) root = root && atoi(e) != 0;
+        if (const char* e = knob("TGX_ROOT")) root = root && atoi(e) != 0;
         while (waves > 1 && tgx::encode4_lds_bytes(waves, ppl, root) > (160u * 1024u) / (uint32_t)bpc) waves--;
         {
             // The geometry must really fit: a block's waves are dealt round-robin to the four SIMDs, so
@@ -690,7 +619,9 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             1, std::min<uint64_t>((p.n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
         unsigned long long* d_stamps = nullptr;
         const size_t n_stamp_waves = (size_t)blocks4 * (size_t)waves;
-        if (const char* e = getenv("TGX_STAMPS")) {
+        // (stamp buffers of the diagnostic runs: a failing call between allocation and release ends the process's
+        // usefulness for diagnosis anyway; they are only ever allocated with TGX_DEBUG=1)
+        if (const char* e = debug_on() ? getenv("TGX_STAMPS") : nullptr) {
             if (*e == '1' && dropout <= 0.0 && ppl == 1) {
                 HIP_TRY(hipMalloc((void**)&d_stamps, n_stamp_waves * 64));
                 HIP_TRY(hipMemsetAsync(d_stamps, 0, n_stamp_waves * 64, m->stream));
@@ -729,24 +660,13 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             (void)hipFree(d_stamps);
             p.stamps = nullptr;
         }
-        if (n_redo4) {  // long samples whose ring slot ran out of pool entries: few, so their serial chains are the cost
-            tgx::EncodeParams r4 = p;
-            r4.order = c->d_counts;
-            r4.n_samples = n_redo4;
-            r4.stamps = nullptr;
-            HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
-            const uint32_t b4 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_redo4 + 19) / 20, (uint64_t)m->num_cus));
-            time_begin(m, "encode4_kernel");
-            HIP_TRY(tgx::launch_encode4(r4, 4, 5, b4, false, m->stream));
-            time_end(m);
-        }
         p.order = c->d_order;
         p.n_samples = c->n_samples;
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
         unsigned long long* d_tstamps = nullptr;
         const size_t n_twaves = (size_t)blocks_t * 4;
-        if (const char* e = getenv("TGX_STAMPS")) {
+        if (const char* e = debug_on() ? getenv("TGX_STAMPS") : nullptr) {
             if (*e == '2') {
                 HIP_TRY(hipMalloc((void**)&d_tstamps, n_twaves * 64));
                 HIP_TRY(hipMemsetAsync(d_tstamps, 0, n_twaves * 64, m->stream));
@@ -872,42 +792,29 @@ static tgx_status ensure_encode_tables(tgx_model* m) {
     // the bytes -> id table and the 8-byte records are independent: the first is built on a second host thread
     // while this one builds the second (each ~50 ms at 500 000 tokens)
     const bool want_hash = m->lm <= 32 && m->scores_finite;
-    const bool want_trie8 = m->lm <= 16 && m->scores_finite && m->flat.table.size() < (1u << 23);
+    const bool want_trie8 = m->lm <= 16 && m->scores_finite && m->flat.table.size() < (1u << 24);
     std::thread hash_builder;
     if (want_hash && !m->tokhash_host_built)
         hash_builder = std::thread([m]() { tgx::build_tok_hash(m->vocab_bytes.data(), m->vocab_offs.data(), m->vocab_size, &m->tokhash); });
     tgx::Trie8 t8;
-    if (want_trie8) {
-        uint32_t max_hot = kE5MaxHot;
-        if (const char* e = getenv("TGX_E5_MAX_HOT")) {  // tests: a small table forces the cold-value paths
-            const int v = atoi(e);
-            if (v >= 0 && v <= (int)kE5MaxHot) max_hot = (uint32_t)v;
-        }
-        tgx::build_trie8(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), max_hot, kE5MaxHotCold, &t8);
-    }
+    if (want_trie8) tgx::build_trie8(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), &t8);
     if (hash_builder.joinable()) hash_builder.join();
-    if (want_hash && m->tokhash.ok) {
+    // (a failure part-way leaves the tables that exist in place, pointers set: the next call finds them — nothing is
+    // allocated twice — and tgx_model_destroy frees them)
+    if (want_hash && m->tokhash.ok && !m->d_tokhash) {
         const size_t hb = m->tokhash.slots.size() * sizeof(tgx::TokHashEntry);
         HIP_TRY(hipMalloc(&m->d_tokhash, hb));
         HIP_TRY(hipMemcpyAsync(m->d_tokhash, m->tokhash.slots.data(), hb, hipMemcpyHostToDevice, m->stream));
     }
-    if (want_trie8 && m->d_tokhash) {
+    if (want_trie8 && t8.ok && m->d_tokhash) {
         const size_t ns = t8.rec.size();
-        HIP_TRY(hipMalloc(&m->d_trie8, ns * sizeof(tgx::Trie8Rec)));
-        HIP_TRY(hipMalloc((void**)&m->d_cold_scores, ns * 8));
-        HIP_TRY(hipMalloc((void**)&m->d_hot, std::max<size_t>(8, t8.hot.size() * 8)));
+        if (!m->d_trie8) HIP_TRY(hipMalloc(&m->d_trie8, ns * sizeof(tgx::Trie8Rec)));
+        if (!m->d_values) HIP_TRY(hipMalloc((void**)&m->d_values, t8.values.size() * 8));
         HIP_TRY(hipMemcpy(m->d_trie8, t8.rec.data(), ns * sizeof(tgx::Trie8Rec), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(m->d_cold_scores, t8.cold_scores.data(), ns * 8, hipMemcpyHostToDevice));
-        if (!t8.hot.empty()) HIP_TRY(hipMemcpy(m->d_hot, t8.hot.data(), t8.hot.size() * 8, hipMemcpyHostToDevice));
-        m->n_hot = (uint32_t)t8.hot.size();
+        HIP_TRY(hipMemcpy(m->d_values, t8.values.data(), t8.values.size() * 8, hipMemcpyHostToDevice));
+        m->n_values = (uint32_t)t8.values.size() - 1u;
+        m->value_coverage = std::move(t8.coverage);
         m->root_base8 = t8.root_base;
-        m->hot_coverage = t8.hot_coverage;
-        m->has_cold = false;
-        for (const tgx::Trie8Rec& q : t8.rec)
-            if (q.sref & tgx::kTrie8Cold) {
-                m->has_cold = true;
-                break;
-            }
         m->have_trie8 = true;
     }
     HIP_TRY(hipStreamSynchronize(m->stream));
@@ -1067,8 +974,7 @@ void tgx_model_destroy(tgx_model* m) {
     if (m->d_trie_rev_w) (void)hipFree(m->d_trie_rev_w);
     if (m->d_tokhash) (void)hipFree(m->d_tokhash);
     if (m->d_trie8) (void)hipFree(m->d_trie8);
-    if (m->d_cold_scores) (void)hipFree(m->d_cold_scores);
-    if (m->d_hot) (void)hipFree(m->d_hot);
+    if (m->d_values) (void)hipFree(m->d_values);
     if (m->d_tokid) (void)hipFree(m->d_tokid);
     if (m->d_ctrl) (void)hipFree(m->d_ctrl);
     if (m->h_ctrl) (void)hipHostFree(m->h_ctrl);
@@ -1110,24 +1016,25 @@ uint64_t tgx_flat_trie_search(const tgx_flat_trie* t, const uint8_t* s, uint64_t
 uint64_t tgx_flat_trie_search8(const tgx_flat_trie* t, const uint8_t* bytes, const uint64_t* offs, const double* scores,
                                uint32_t max_hot, const uint8_t* s, uint64_t n, uint32_t* ids, uint32_t* lens,
                                uint64_t cap, uint32_t* n_hot, uint64_t* n_cold, double* hot_coverage) {
-    if (!t || t->flat.table.size() >= (1u << 23)) return ~0ULL;
+    if (!t) return ~0ULL;
     static const uint64_t zero_offs[1] = {0};
-    // (test infrastructure: the records of the last max_hot asked for are kept on the handle)
+    // (test infrastructure: the records are built on first use and kept on the handle)
     tgx_flat_trie* tm = const_cast<tgx_flat_trie*>(t);
-    if (!tm->t8 || tm->t8_max_hot != max_hot) {
+    if (!tm->t8) {
         tm->t8.reset(new tgx::Trie8());
-        tgx::build_trie8(t->flat, offs ? offs : zero_offs, scores, max_hot, max_hot, tm->t8.get());
-        tm->t8_max_hot = max_hot;
+        tgx::build_trie8(t->flat, offs ? offs : zero_offs, scores, tm->t8.get());
     }
     const tgx::Trie8& t8 = *tm->t8;
     (void)bytes;
-    if (n_hot) *n_hot = (uint32_t)t8.hot.size();
+    if (!t8.ok) return ~0ULL;  // more than 65 535 distinct score values (or too many slots): no 8-byte records
+    const uint32_t n_values = (uint32_t)t8.values.size() - 1u, k = std::min(max_hot, n_values);
+    if (n_hot) *n_hot = k;
     if (n_cold) {
-        uint64_t k = 0;
-        for (const tgx::Trie8Rec& q : t8.rec) k += (q.sref & tgx::kTrie8Cold) ? 1 : 0;
-        *n_cold = k;
+        uint64_t c = 0;
+        for (const tgx::Trie8Rec& q : t8.rec) c += (q.sref & tgx::kTrie8RankMask) > k ? 1 : 0;
+        *n_cold = c;
     }
-    if (hot_coverage) *hot_coverage = t8.hot_coverage;
+    if (hot_coverage) *hot_coverage = t8.coverage[k];
     return tgx::trie8_common_prefix_search(t8, t->flat, s, n, ids, lens, cap);
 }
 void tgx_flat_trie_stats(const tgx_flat_trie* t, uint64_t* n_slots, uint64_t* n_nodes,
@@ -1410,7 +1317,7 @@ tgx_status tgx_encode_batch_host(tgx_model* m, const uint8_t* text, const uint64
     {
         uint64_t chunk = 256ull << 20;  // a chunk's pass is bounded below by the serial chain of its longest sample: few, large chunks
         if (dropout > 0.0) chunk = ~0ull;
-        if (const char* e = getenv("TGX_E2E_CHUNK_MB")) {
+        if (const char* e = knob("TGX_E2E_CHUNK_MB")) {
             const long v = atol(e);
             if (v > 0 && dropout <= 0.0) chunk = (uint64_t)v << 20;
         }
@@ -1647,7 +1554,7 @@ tgx_status tgx_count_tokens(tgx_model* m, tgx_corpus* c, uint64_t* freq) {
         tgx_result_free(r);
         return fail(TGX_ERR_UNSUPPORTED, "frequency pass over more than 2^32-1 tokens per call");
     }
-    if (T && m->vocab_size <= tgx::kHistMaxVocab && !getenv("TGX_FREQ_SORT")) {
+    if (T && m->vocab_size <= tgx::kHistMaxVocab && !knob("TGX_FREQ_SORT")) {
         // the vocabulary's counters fit a block's LDS: one private histogram per block (pairs.hip)
         unsigned long long* d_hist = nullptr;
         const size_t hb = (size_t)m->vocab_size * 8 + 256;
@@ -1989,7 +1896,7 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     int32_t* d_aexp = nullptr;  // block exponents of alpha (linear-domain kernels)
     const size_t xbytes = (size_t)((N >> 4) + K + 128) * 4;
     // TGX_ESTEP=log keeps the log-domain kernels (A/B timing, tests of both)
-    const char* force_log = getenv("TGX_ESTEP");
+    const char* force_log = knob("TGX_ESTEP");
     const bool linear = m->estep_linear_ok && !(force_log && strcmp(force_log, "log") == 0);
     auto cleanup = [&](tgx_status s2) {
         // kernels already queued may still write these buffers: no other handle may take them from the pool yet
@@ -2060,7 +1967,7 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             if (i == 0 || tf < bf * 0.95) { bf = tf; eppl_fwd = 1 << i; }
             if (i == 0 || tb < bb * 0.95) { bb = tb; eppl_bwd = 1 << i; }
         }
-        if (const char* e = getenv("TGX_EPPL")) {
+        if (const char* e = knob("TGX_EPPL")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) eppl_fwd = eppl_bwd = v;
         }
@@ -2106,11 +2013,23 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     time_end(m);
     std::vector<double> h(n_rev);
     double hz = 0.0;
+    // The backward kernel of the long-token builds has an overflow list of its own (matches of 17..32 bytes by END
+    // position and window; the forward kernel counts them by START position), so it can run out where the forward
+    // kernel did not: the flag is read again with the results, and a pass that raised it is discarded.
+    unsigned long long flag_bwd = 0;
     if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(&flag_bwd, m->d_ctrl + 5, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipMemcpyAsync(h.data(), d_sum, n_rev * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipMemcpyAsync(&hz, d_z, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipStreamSynchronize(m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "E-step pass failed: %s", hipGetErrorString(hipGetLastError())));
+    if (use_linear && flag_bwd != 0) {  // nothing of this pass reaches `expected`
+        if (long_tokens && fallback) {
+            *fallback = true;  // the generic kernel redoes it (tgx_estep)
+            return cleanup(TGX_OK);
+        }
+        return cleanup(fail(TGX_ERR_DEVICE, "E-step backward kernel raised range_flag %llu after a clean forward pass", flag_bwd));
+    }
     m->last_alg_bytes = N + 8 * (S + 1) + 8ull * m->vocab_size;
     const unsigned long long bad = m->h_ctrl[0];
     if (bad != ~0ULL) {  // nothing of a failed pass reaches the caller's `expected`
@@ -2142,12 +2061,12 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
     m->n_timed = 0;
     const uint64_t S = c->n_samples, N = c->n_bytes;
     {
-        const char* force = getenv("TGX_PATH");
+        const char* force = knob("TGX_PATH");
         const bool rows = m->scores_finite && !(force && strcmp(force, "fused") == 0);
         if (rows && m->lm <= 16) return estep_rows4(m, c, snippet_len, dropout, seed, expected, logz_sum, nullptr);
         // tokens of 17..32 bytes (after `merge`): the linear-domain kernels' long-token builds; the generic kernel
         // below where they cannot do the pass
-        const char* force_log = getenv("TGX_ESTEP");
+        const char* force_log = knob("TGX_ESTEP");
         if (rows && m->lm <= 32 && m->estep_linear_ok && !(force_log && strcmp(force_log, "log") == 0)) {
             bool fallback = false;
             st = estep_rows4(m, c, snippet_len, dropout, seed, expected, logz_sum, &fallback);
@@ -2248,5 +2167,7 @@ uint32_t tgx_last_encode_waves_per_cu(const tgx_model* m) { return m ? (uint32_t
 uint64_t tgx_last_algorithmic_bytes(const tgx_model* m) { return m ? m->last_alg_bytes : 0; }
 uint64_t tgx_last_encode_redo_samples(const tgx_model* m) { return m ? m->last_redo_samples : 0; }
 uint64_t tgx_last_encode_long_samples(const tgx_model* m) { return m ? m->last_long_samples : 0; }
+uint32_t tgx_model_score_values(const tgx_model* m) { return m && m->have_trie8 ? m->n_values : 0u; }
+uint32_t tgx_last_encode_hot_values(const tgx_model* m) { return m ? m->last_n_hot : 0u; }
 
 }  // extern "C"

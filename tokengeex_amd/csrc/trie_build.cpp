@@ -264,19 +264,18 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
 }
 
 // ---- 8-byte label-checked records + score table (encode5_kernel) ----------------------------------------
-void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, uint32_t max_hot, uint32_t max_hot_cold, Trie8* out) {
+void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, Trie8* out) {
     const uint32_t n_slots = (uint32_t)ft.table.size();
     out->rec.assign(n_slots, Trie8Rec{0, 0});
-    out->cold_scores.assign(n_slots, 0.0);
-    out->hot.clear();
-    out->hot_coverage = 1.0;
+    out->values.clear();
+    out->coverage.clear();
+    out->ok = false;
     // distinct score values (by bit pattern) of the tokens that can match, weighted by how often their
     // tokens are expected to match: a token of probability mass w and length l starts at about w / l of
     // the positions (its Viterbi share; the proxy only has to rank the values)
     struct Val {
         uint64_t bits;
         double weight;
-        uint32_t first_slot;
     };
     std::vector<std::pair<uint64_t, uint32_t>> by_bits;  // (score bits, slot) of terminal slots
     by_bits.reserve(n_slots / 2);
@@ -287,7 +286,7 @@ void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores,
     std::vector<uint32_t> val_of(by_bits.size());  // by_bits index -> vals index
     double total_w = 0.0;
     for (size_t i = 0; i < by_bits.size(); i++) {
-        if (i == 0 || by_bits[i].first != by_bits[i - 1].first) vals.push_back(Val{by_bits[i].first, 0.0, by_bits[i].second});
+        if (i == 0 || by_bits[i].first != by_bits[i - 1].first) vals.push_back(Val{by_bits[i].first, 0.0});
         const uint32_t id = ft.tokid[by_bits[i].second];
         const double len = (double)std::max<uint64_t>(1, offs[id + 1] - offs[id]);
         double w = std::exp(scores[id]) / len;
@@ -296,30 +295,38 @@ void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores,
         total_w += w;
         val_of[i] = (uint32_t)vals.size() - 1;
     }
+    if (vals.size() > kTrie8MaxValues || n_slots >= (1u << 24)) return;  // ranks are 16 bits, bases 24
     std::vector<uint32_t> order(vals.size());
     for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         if (vals[a].weight != vals[b].weight) return vals[a].weight > vals[b].weight;
         return vals[a].bits < vals[b].bits;
     });
-    // all values in the table if they fit; otherwise a smaller table, which leaves the kernels room for the
-    // per-wave pools the cold values go through (table + pools share 64 KiB of 16-bit addresses)
-    const uint32_t n_hot = order.size() <= max_hot ? (uint32_t)order.size() : std::min(max_hot, max_hot_cold);
-    std::vector<uint32_t> rank(vals.size(), 0xFFFFFFFFu);
-    double hot_w = 0.0;
-    out->hot.resize(n_hot);
-    for (uint32_t r = 0; r < n_hot; r++) {
-        rank[order[r]] = r;
-        out->hot[r] = vals[order[r]].bits;
-        hot_w += vals[order[r]].weight;
+    std::vector<uint32_t> rank(vals.size(), 0u);
+    out->values.resize(order.size() + 1);
+    out->coverage.resize(order.size() + 1);
+    {
+        const double ninf = -__builtin_huge_val();
+        std::memcpy(&out->values[0], &ninf, 8);
+        out->coverage[0] = 0.0;
     }
-    if (total_w > 0.0 && n_hot < order.size()) out->hot_coverage = std::min(hot_w / total_w, 1.0 - 1e-12);
+    double seen_w = 0.0;
+    for (uint32_t r = 0; r < order.size(); r++) {
+        rank[order[r]] = r + 1u;
+        out->values[r + 1u] = vals[order[r]].bits;
+        seen_w += vals[order[r]].weight;
+        out->coverage[r + 1u] = total_w > 0.0 ? std::min(seen_w / total_w, 1.0) : 1.0;
+    }
+    out->coverage.back() = 1.0;  // all values (the running sum need not end exactly on the total)
     std::vector<uint32_t> sref(n_slots, 0);
-    for (size_t i = 0; i < by_bits.size(); i++) {
-        const uint32_t t = by_bits[i].second, r = rank[val_of[i]];
-        // hot: byte offset of the value in the kernel's LDS score region (entry 0 is -inf); cold: the slot
-        sref[t] = kTrie8Terminal | (r != 0xFFFFFFFFu ? 8u * (r + 1u) : (kTrie8Cold | t));
-        std::memcpy(&out->cold_scores[t], &by_bits[i].first, 8);
+    for (size_t i = 0; i < by_bits.size(); i++) sref[by_bits[i].second] = rank[val_of[i]];
+    // child masks: the parent of a used slot t is ft.table[t].check, its edge byte ft.label[t]
+    uint32_t root_mask = 0;
+    for (uint32_t t = 1; t < n_slots; t++) {
+        if (ft.table[t].check == kNoParent) continue;
+        const uint32_t parent = ft.table[t].check, bit = 1u << ((uint32_t)ft.label[t] >> 4);
+        if (parent == 0u) root_mask |= bit;
+        else sref[parent] |= bit << 16;
     }
     for (uint32_t t = 0; t < n_slots; t++) {
         Trie8Rec& q = out->rec[t];
@@ -334,19 +341,24 @@ void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores,
         }
     }
     out->root_base = ft.inner[0] ? (ft.table[0].base & ~kTerminalBit) : kTrie8LeafBase;
+    out->root_mask = root_mask;
+    out->ok = true;
 }
 
+// host twin of the device walk over the 8-byte records, child masks included
 uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const uint8_t* s, uint64_t n, uint32_t* ids,
                                     uint32_t* lens, uint64_t cap) {
-    uint32_t base = t8.root_base;
+    uint32_t base = t8.root_base, mask = t8.root_mask;
     uint64_t found = 0;
     for (uint64_t i = 0; i < n; i++) {
+        if (!((mask >> (s[i] >> 4)) & 1u)) break;  // no child in this byte's class: the walk ends without a probe
         const uint32_t t = base ^ s[i];
         if (t >= t8.rec.size()) break;
         const uint32_t r = t8.rec[t].rec;
         if ((r & 0xFFu) != s[i]) break;
         base = r >> 8;
-        if (t8.rec[t].sref & kTrie8Terminal) {
+        mask = t8.rec[t].sref >> 16;
+        if (t8.rec[t].sref & kTrie8RankMask) {
             if (found < cap) {
                 ids[found] = ft.tokid[t];
                 lens[found] = (uint32_t)(i + 1);

@@ -45,30 +45,35 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
                      uint32_t vocab_size, FlatTrie* out);
 
 // Label-checked 8-byte records over the SAME slot assignment (encode5_kernel): the walk keeps only `base`,
-//   t = base ^ byte;  {rec, sref} = table[t];  valid iff (rec & 0xFF) == byte;  base = rec >> 8;  terminal = sref bit 31
+//   t = base ^ byte;  {rec, sref} = table[t];  valid iff (rec & 0xFF) == byte;  base = rec >> 8
 // which is exact because build_flat_trie gives every node with children a base of its own (if slot t passes
 // the check for (base, byte) its owner's base is t ^ byte = base) whose low byte is neither 0xFE nor 0xFF:
 // leaves point at base 0xFE of block 0 (the root's block, otherwise empty) and an unused slot t carries the
-// label (t ^ 0xFF) & 0xFF, so neither can pass.  `sref` of a terminal slot says where its score is: the byte
-// offset (below 64 KiB) of its VALUE in the kernel's LDS score table (distinct score values, the ones expected to match most
-// often first; entry 0 of the table is -inf), or kTrie8Cold | slot when the value did not make the table
-// (cold_scores[slot] in HBM).  generate-style vocabularies score tokens by integer counts and have a few
-// thousand distinct values; after an M-step every token has its own.
+// label (t ^ 0xFF) & 0xFF, so neither can pass.
+// `sref` (round 3): bits 0..15 = RANK of the token's score value, 0 for a slot no token ends at — the distinct
+// score values of the vocabulary are ranked by how often their tokens are expected to match (1 = hottest), and
+// `values[rank]` is the table the kernels read: its first entries from a copy in LDS, the rest from HBM / L2.
+// A vocabulary after an M-step has one value per token (src/prune.rs:143-151), so ranks must cover 65 535 values;
+// a vocabulary with more distinct values than that has no Trie8 (ok == false: the 16-byte records serve it).
+// bits 16..31 = CHILD MASK: bit (c >> 4) is set iff the node has a child whose edge byte c' has c' >> 4 == c >> 4.
+// A walk whose next text byte has its bit clear ends without a gather: 3.46 -> 2.55 gathers per position below
+// the root level on the bench corpus (a leaf has mask 0; 87 % of the failing probes are gone).
 struct Trie8Rec {
     uint32_t rec;   // label | base << 8
-    uint32_t sref;  // 0 for a slot no token ends at; else kTrie8Terminal | (LDS byte offset, or kTrie8Cold | slot)
+    uint32_t sref;  // rank | child mask << 16
 };
-constexpr uint32_t kTrie8Terminal = 0x80000000u;
-constexpr uint32_t kTrie8Cold = 0x40000000u;
+constexpr uint32_t kTrie8RankMask = 0xFFFFu;
+constexpr uint32_t kTrie8MaxValues = 65535u;
 constexpr uint32_t kTrie8LeafBase = 0xFEu;
 struct Trie8 {
-    std::vector<Trie8Rec> rec;        // n_slots
-    std::vector<double> cold_scores;  // n_slots: score of every terminal slot
-    std::vector<uint64_t> hot;        // bit patterns of the LDS table's values, entry i at byte offset 8 (i + 1)
+    std::vector<Trie8Rec> rec;     // n_slots
+    std::vector<uint64_t> values;  // bit patterns: values[0] = -inf ("no token"), values[r] = the value of rank r
+    std::vector<double> coverage;  // coverage[k] = expected share of the matches whose value has rank <= k (k = 0 .. n)
     uint32_t root_base = 0;
-    double hot_coverage = 1.0;        // expected share of the matches whose score is in the table
+    uint32_t root_mask = 0;        // child mask of the root (bits 0..15)
+    bool ok = false;
 };
-void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, uint32_t max_hot, uint32_t max_hot_cold, Trie8* out);
+void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, Trie8* out);
 uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const uint8_t* s, uint64_t n, uint32_t* ids,
                                     uint32_t* lens, uint64_t cap);
 
@@ -147,6 +152,5 @@ extern "C" int tgx_prune_alternatives_flat(const tgx::FlatTrie* flat_trie, const
 // host-only handle of include/tgx.h's tgx_flat_trie_* functions (tgx_api.cpp, prune_host.cpp)
 struct tgx_flat_trie {
     tgx::FlatTrie flat;
-    std::unique_ptr<tgx::Trie8> t8;  // tgx_flat_trie_search8: records of the last max_hot asked for
-    uint32_t t8_max_hot = 0;
+    std::unique_ptr<tgx::Trie8> t8;  // tgx_flat_trie_search8: built on first use
 };

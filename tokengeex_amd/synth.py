@@ -234,6 +234,19 @@ def build_vocab(text: np.ndarray, size: int, max_token_length: int = 16):
     return [tkn for tkn, _ in vocab], scores
 
 
+def load_spec_vocab(size: int):
+    """The benchmark vocabulary of SURVEY.md section 8(d): build_vocab over a fixed 64 MiB slice of the mixed corpus
+    (seed offset 0), 32 000 or 65 536 entries of at most 16 bytes — minutes of numpy, so it is committed compressed
+    (tests/golden/vocab_<size>.npz, written by tools/make_spec_vocab.py).  -> (tokens, scores, slice MiB)"""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", f"vocab_{size}.npz")
+    z = np.load(path)
+    fb = z["flat"].tobytes()
+    o = np.concatenate([[0], np.cumsum(z["lens"].astype(np.int64))])
+    toks = [fb[o[i]:o[i + 1]] for i in range(o.size - 1)]
+    return toks, z["uscores"][z["inv"]].astype(np.float64), int(z["slice_mib"][0])
+
+
 def random_vocab(rng: np.random.Generator, text: bytes, n_multi: int, max_len: int = 16,
                  all_bytes: bool = True, tie_fraction: float = 0.2):
     """Small random vocabulary for parity tests: (all) single bytes + substrings
