@@ -144,13 +144,12 @@ uint64_t tgx_flat_trie_search(const tgx_flat_trie *t, const uint8_t *s, uint64_t
 void tgx_flat_trie_stats(const tgx_flat_trie *t, uint64_t *n_slots, uint64_t *n_nodes,
                          uint32_t *max_token_len);
 /* The same search over the 8-byte label-checked records encode5_kernel walks (built from the same slot
- * assignment: the walk keeps only `base`, compares a record's label with the text byte and ends without a
- * probe where the node's child mask rules the next byte out), plus figures of the score table for a copy of
- * max_hot values in LDS: *n_hot = values in that copy (ranks 1..n_hot of the vocabulary's distinct score
- * values), *n_cold terminal slots whose value is outside it (read from HBM / L2 by the kernels),
- * *hot_coverage the expected share of matches the copy serves.  Any out pointer may be NULL.  Returns the
- * number of matches, or UINT64_MAX when the records cannot be built (more than 65 535 distinct score values,
- * or >= 2^24 slots). */
+ * assignment: the walk keeps only the record and compares its label with the text byte), plus figures of the
+ * score table for a copy of max_hot values in LDS: *n_hot = values in that copy (ranks 1..n_hot of the
+ * vocabulary's distinct score values), *n_cold terminal slots whose value is outside it (read from HBM / L2 by
+ * the kernels), *hot_coverage the expected share of matches the copy serves.  Any out pointer may be NULL.
+ * Returns the number of matches, or UINT64_MAX when the records cannot be built (more than 65 535 distinct
+ * score values, or more than 2^21 slots). */
 uint64_t tgx_flat_trie_search8(const tgx_flat_trie *t, const uint8_t *bytes, const uint64_t *offs,
                                const double *scores, uint32_t max_hot, const uint8_t *s, uint64_t n,
                                uint32_t *ids, uint32_t *lens, uint64_t cap, uint32_t *n_hot,

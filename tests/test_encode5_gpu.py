@@ -37,6 +37,25 @@ def test_values_outside_the_lds_copy_are_read_by_the_relaxing_lane(monkeypatch, 
         assert_same_encoding(nat, ora, flat, offs)
 
 
+def test_every_match_cold_and_sixteen_matches_per_position(monkeypatch):
+    """No value in the LDS copy and a text in which every position has sixteen matches: every one of the 1 024
+    entries of a group of 16 positions is read from L2 by the relaxing lane."""
+    monkeypatch.setenv("TGX_E5_HOT", "0")
+    toks = [bytes([c]) for c in range(256)] + [b"a" * k for k in range(2, 17)] + [b"ab", b"ba", b"abab"]
+    rng = np.random.default_rng(41)
+    scores = -(rng.random(len(toks)) * 6.0 + 1.0)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    texts = [b"a" * 5000, b"ab" * 700 + b"a" * 900, b"a" * 15, b"a" * 16, b"a" * 17, b"x" + b"a" * 300 + b"y", b""]
+    flat, offs = synth.make_corpus(1 << 20, "mixed", seed_offset=77, max_len=20000)
+    f, o = tgx.pack(texts + [flat[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(40)])
+    assert_same_encoding(nat, ora, f, o)
+    assert "encode5_kernel" in nat.last_kernel_times() and nat.last_encode_hot_values() == 0
+    assert_same_encoding(nat, ora, f, o, dropout=0.3, seed=5)
+    for ppl in ("1", "2"):
+        monkeypatch.setenv("TGX_PPL", ppl)
+        assert_same_encoding(nat, ora, f, o)
+
+
 def test_which_kernel_serves_which_vocabulary(monkeypatch):
     """generate-style vocabularies (scores are logs of integer counts: a few thousand distinct values) AND
     vocabularies in which every token has its own score (after an M-step or merge: src/prune.rs:143-151,
@@ -55,7 +74,7 @@ def test_which_kernel_serves_which_vocabulary(monkeypatch):
     assert_same_encoding(nat2, ora2, flat, offs)
     kt = nat2.last_kernel_times()
     assert "encode5_kernel" in kt and "encode4_kernel" not in kt and nat2.last_encode_redo_samples() == 0
-    assert nat2.score_values() == len(set(sc2.tolist())) > nat2.last_encode_hot_values() >= 3000
+    assert nat2.score_values() == len(set(sc2.tolist())) > nat2.last_encode_hot_values() >= 3000   # (the 2 MiB batch has rows for 16 waves)
     # TGX_PATH=rows4 still forces round 1's kernel (A/B timing): same ids
     monkeypatch.setenv("TGX_PATH", "rows4")
     assert_same_encoding(nat2, ora2, flat, offs)
@@ -158,7 +177,7 @@ def test_vocabulary_with_distinct_scores_by_default(monkeypatch):
     assert_same_encoding(nat, ora, flat, offs)
     kt = nat.last_kernel_times()
     assert "encode5_kernel" in kt and "encode4_kernel" not in kt and nat.last_encode_redo_samples() == 0
-    assert nat.last_encode_hot_values() < nat.score_values() == 12000
+    assert nat.last_encode_hot_values() <= nat.score_values() == 12000  # (a batch this small gets few waves per block: every value fits)
     f2, o2 = synth.make_corpus(16 << 20, "mixed", seed_offset=56)
     assert_same_encoding(nat, ora, f2, o2)
     kt = nat.last_kernel_times()

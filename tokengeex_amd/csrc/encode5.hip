@@ -4,9 +4,12 @@
 // the texture-address path at 1.6 cycles per 16-byte gather lane, and 8 KiB of LDS per wave and 64
 // positions capping the waves per CU):
 //
-//   * 8-byte label-checked trie records (trie_build.h: Trie8Rec).  A walk keeps only `base`; a step is one
-//     8-byte gather {label | terminal | next base, score reference} (0.9 cycles per lane, measured:
-//     profiles/r02/a_gather_8byte_records.txt) and one compare of the label with the text byte.
+//   * 8-byte label-checked trie records (trie_build.h: Trie8Rec).  A walk keeps only the record; a step is one
+//     8-byte gather {8 * base | label << 24, rank of the score value} (0.9 cycles per lane, measured:
+//     profiles/r02/a_gather_8byte_records.txt), one compare of the label with the text byte and — round 3 — three
+//     instructions for the next address ((rec ^ byte << 3) & 0xFFFFFF, dead walks to record 0): the kernel is
+//     bound by vector-instruction issue, every instruction of a step counts 43 times per
+//     256 positions.
 //   * scores are not carried through the match buffer.  The distinct score VALUES of the vocabulary are ranked
 //     by how often their tokens are expected to match (trie_build.h: Trie8) and a match is the 16-bit RANK of its
 //     value ("no token" = rank 0 = a -inf entry): 2 KiB per wave and 64 positions instead of 8 KiB.  The first
@@ -15,9 +18,6 @@
 //     the LDS reads of its group).  Every vocabulary with at most 65 535 distinct values runs this kernel — after
 //     an M-step every token has its own (src/prune.rs:143-151) — and nothing can overflow: round 2 sent cold
 //     values through per-wave pools in LDS whose overflow cost a second pass over the samples concerned.
-//   * round 3: child masks.  A record carries a 16-bit mask of the byte classes (byte >> 4) its node has children
-//     in; a walk whose next byte is ruled out ends without the failing probe that used to end it (3.46 -> 2.55
-//     gathers per position below the root level).
 //   * the PPL walks of a lane are staggered (Walk5), and the relaxation runs on relax5_step (device_common.h).
 //
 // Same candidate order and strict '>' as encode4_kernel, so the back-pointer bytes and the per-sample status
@@ -29,6 +29,30 @@
 #include "kernels.h"
 
 namespace tgx {
+
+// LDS accesses by byte offset (32-bit LDS pointers): no 64-bit flat address arithmetic, no "+ base of the dynamic
+// LDS" per access — the kernel folds that base (0 when a kernel has no static LDS) into its per-lane constants once
+template <class T>
+__device__ __forceinline__ T lds_ld(uint32_t off) { return *(const __attribute__((address_space(3))) T*)(uintptr_t)off; }
+template <class T>
+__device__ __forceinline__ void lds_st(uint32_t off, T v) { *(__attribute__((address_space(3))) T*)(uintptr_t)off = v; }
+
+// The trie records and the value table are read through buffer resources: `buffer_load_dwordx2 v, voffset, rsrc, 0
+// offen` takes a 32-bit byte offset per lane (a global_load of base + offset needs a 64-bit add per lane, or a form
+// the compiler only picks for scaled indices), and an offset beyond the table reads zeros instead of faulting.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);  // raw buffer, 32-bit data format
+}
+__device__ __forceinline__ uint2 buf_ld8(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ double buf_ld_f64(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
 
 // match-index buffer of one 16-position group: four sample rows of 16 columns x 16 start positions x 2 bytes
 // = 2 KiB per wave and group, 512-byte aligned.  Entry (start u, len) of row r: r * 512 + ((len - 1 + u) & 15) * 32
@@ -42,8 +66,7 @@ constexpr uint32_t kE5GroupBytes = 4 * kE5RowStride;  // 2048
 
 template <int PPL>
 struct WalkCtx {
-    const uint2* __restrict__ trie;
-    unsigned char* smem;
+    __amdgpu_buffer_rsrc_t trie;  // Trie8Rec[], addressed by byte offset
     uint32_t s, l32;
     double dropout;
     uint64_t seed;
@@ -52,14 +75,15 @@ struct WalkCtx {
 // ---- the trie walks of a lane (PPL start positions), unrolled over the depth D by template recursion (with
 // its early exit inside, hipcc's unroller gives up on the plain loop and the text bytes end up selected by
 // v_cndmask chains).  The PPL walks are STAGGERED: a level consumes the record of walk g and at once requests
-// walk g's next record, so while one walk's record is examined (about 25 instructions) the gathers of the other
-// walks are in flight (vector loads return in order: the wait for walk g's record leaves the PPL - 1 younger ones
-// outstanding).  With all gathers of a depth issued together and waited for together a step of two walks took
-// 890 cycles against 540 for one.
-// (Every lane issues every gather, finished walks from slot 0: a load that only some paths issue would force
+// walk g's next record, so while one walk's record is examined the gathers of the other walks are in flight
+// (vector loads return in order: the wait for walk g's record leaves the PPL - 1 younger ones outstanding).
+// With all gathers of a depth issued together and waited for together a step of two walks took 890 cycles
+// against 540 for one.
+// (Every lane issues every gather, finished walks from record 0: a load that only some paths issue would force
 // the compiler to wait for ALL outstanding loads at every use — in-order counters cannot name a load that may
-// not exist — and the stagger would be lost.  For the same reason the hottest slots are NOT read from an LDS
-// copy: tried, 2 % at best, a step still waits for its slowest lane, which goes to L2.)
+// not exist — and the stagger would be lost; lanes reading record 0 cost the texture path next to nothing,
+// profiles/r03/d_gather3_dead_lanes.txt.  For the same reason the hottest slots are NOT read from an LDS copy:
+// tried, 2 % at best, a step still waits for its slowest lane, which goes to L2.)
 template <bool DROPOUT, int PPL, int D>
 struct Walk5 {
     // rec[g], c[g]: record and text byte of depth D of walk g (the load may still be in flight)
@@ -70,20 +94,21 @@ struct Walk5 {
         bool any = false;
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
-            alive[g] = alive[g] && ((rec[g].x & 0xFFu) == c[g]);
+            asm("" : "+v"(rec[g].x), "+v"(rec[g].y));  // two 32-bit words (else the 64-bit load is picked apart with 64-bit ops)
+            alive[g] = alive[g] && ((rec[g].x >> 24) == c[g]);
             const uint32_t rank = rec[g].y & 0xFFFFu;  // 0: no token ends here
             bool term = alive[g] && rank != 0u;
-            const uint32_t base = rec[g].x >> 8;
             if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
                 if (term && d >= 1) term = W.dropout < dropout_u01(W.seed, W.s, pg[g], (uint32_t)d + 1u);
             }
-            if (term) *reinterpret_cast<uint16_t*>(W.smem + (wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u))) = (uint16_t)rank;
-            // this walk's next record — unless the node has no child in the next byte's class (child mask)
+            if (term) lds_st<uint16_t>(wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u), (uint16_t)rank);
+            // this walk's next record
             if (D + 1 < 16) {
                 constexpr int e = D + 1 < 16 ? D + 1 : 15;
                 c[g] = (bytes[g][e >> 2] >> ((e & 3) * 8)) & 0xFFu;
-                alive[g] = alive[g] && ((uint32_t)e < maxd[g]) && (((rec[g].y >> 16) >> (c[g] >> 4)) & 1u) != 0u;
-                rec[g] = W.trie[alive[g] ? (base ^ c[g]) : 0u];
+                alive[g] = alive[g] && ((uint32_t)e < maxd[g]);
+                const uint32_t off = (rec[g].x ^ (c[g] << 3)) & 0xFFFFFFu;
+                rec[g] = buf_ld8(W.trie, alive[g] ? off : 0u);
             } else {
                 alive[g] = false;
             }
@@ -101,29 +126,46 @@ struct Walk5<DROPOUT, PPL, 16> {
 };
 
 // The score values of N consecutive steps (from step `first`) of a lane, whose sixteen match indices are the 16-bit
-// ranks in iw[8]: rank * 8 is the byte offset of the value in the table.  The LDS copy holds the first hot_bytes of
-// the table; COLD builds (vocabularies with more values than the copy holds) read the others from the table in HBM /
-// L2 under the cold lanes' EXEC mask.  (The LDS reads are unconditional, at clamped addresses, and exist before the
-// conditional loads — the empty asm: written as `hot ? lds : hbm`, or with the LDS read sinkable, the compiler
-// merges the two into one FLAT load of a selected address, which goes through the texture path for every lane.)
-template <bool COLD, int N>
-__device__ __forceinline__ void e5_scores(const unsigned char* smem, const unsigned char* __restrict__ values, const uint32_t (&iw)[8],
-                                          int first, uint32_t hot_bytes, double (&sv)[N]) {
+// words in iw[8]: index * 8 is the byte offset of the value in the block's LDS — the copy of the first hot_bytes of the
+// value table (at LDS byte offset `tab`).  Requested a quarter group ahead of use.
+template <int N>
+__device__ __forceinline__ void e5_scores_issue(uint32_t tab, const uint32_t (&iw)[8], int first, u32x2_t (&sp)[N]) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int v = first + u;
+        const uint32_t a = (v & 1) ? ((iw[v >> 1] >> 16) << 3) : ((iw[v >> 1] & 0xFFFFu) << 3);
+        sp[u] = lds_ld<u32x2_t>(tab + a);
+    }
+}
+__device__ __forceinline__ double e5_score_value(const u32x2_t& p) { return __hiloint2double((int)p.y, (int)p.x); }
+
+// COLD builds (vocabularies with more distinct score values than the LDS copy holds): an index beyond the copy is
+// the RANK of a value that lives in the rest of the table in HBM / L2 (`cold`: the values from rank n_hot + 1 on),
+// read under the cold lanes' EXEC mask — one exec-masked buffer load per entry in which some lane is cold (~33 of 64
+// per 256 positions when a tenth of the matches are cold), a batch of N entries at a time.  (The LDS reads are
+// unconditional, at clamped addresses, and exist before the conditional loads — the empty asm: written as
+// `hot ? lds : hbm`, or with the LDS read sinkable, the compiler merges the two into one FLAT load of a selected
+// address, which goes through the texture path for every lane.)
+// Three other ways of getting the cold values were built and measured in round 3 (profiles/r03/README.md): moving
+// them into pool slots in LDS before the relaxation, with or without its L2 round trip hidden behind the group
+// before (e5_resolve: +0.4 ... +2.3 ms per GiB against this); unconditional loads whose hot lanes fall outside the
+// buffer, merged by OR (+2.7 ms).  Each removes instructions of one kind and adds more of another.
+template <int N>
+__device__ __forceinline__ void e5_scores_cold(uint32_t tab, __amdgpu_buffer_rsrc_t cold, const uint32_t (&iw)[8], int first,
+                                               uint32_t hot_bytes, double (&sv)[N]) {
     uint32_t a[N];
 #pragma unroll
     for (int u = 0; u < N; ++u) {
         const int v = first + u;
-        a[u] = (v & 1) ? ((iw[v >> 1] >> 13) & 0x7FFF8u) : ((iw[v >> 1] << 3) & 0x7FFF8u);
-        sv[u] = *reinterpret_cast<const double*>(smem + (COLD ? (a[u] < hot_bytes ? a[u] : hot_bytes) : a[u]));
+        a[u] = (v & 1) ? ((iw[v >> 1] >> 16) << 3) : ((iw[v >> 1] & 0xFFFFu) << 3);
+        sv[u] = lds_ld<double>(tab + (a[u] < hot_bytes ? a[u] : 0u));
     }
-    if (COLD) {
-        static_assert(N == 4 || N == 8, "e5_scores: 4 or 8 values at a time");
-        if (N == 8) asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4 % N]), "+v"(sv[5 % N]), "+v"(sv[6 % N]), "+v"(sv[7 % N]));
-        else asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]));
+    static_assert(N == 4 || N == 8, "e5_scores_cold: four or eight values at a time");
+    if (N == 8) asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4 % N]), "+v"(sv[5 % N]), "+v"(sv[6 % N]), "+v"(sv[7 % N]));
+    else asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]));
 #pragma unroll
-        for (int u = 0; u < N; ++u)
-            if (a[u] >= hot_bytes) sv[u] = *reinterpret_cast<const double*>(values + a[u]);
-    }
+    for (int u = 0; u < N; ++u)
+        if (a[u] >= hot_bytes) sv[u] = buf_ld_f64(cold, a[u] - hot_bytes);
 }
 
 // TGX_STAMPS=1 (diagnostic runs only): s_memtime stamps around the phases of an iteration, summed per wave
@@ -146,10 +188,12 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = threadIdx.x >> 6;
     const uint2* __restrict__ trie = reinterpret_cast<const uint2*>(Q.trie8);
+    const __amdgpu_buffer_rsrc_t trie_b = make_rsrc(Q.trie8, Q.trie_bytes);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);  // LDS byte offset of the dynamic LDS (0 here)
     // ---- LDS: [0, 8 (n_hot + 1)) score table (entry 0 = -inf: rank 0 = "no token") | root records | match indices
     double* const score_tab = reinterpret_cast<double*>(smem);
     const uint32_t hot_bytes = 8u * (Q.n_hot + 1u);
-    const unsigned char* __restrict__ values = reinterpret_cast<const unsigned char*>(Q.values);
+    const __amdgpu_buffer_rsrc_t values = make_rsrc(reinterpret_cast<const unsigned char*>(Q.values) + hot_bytes, 8u * (Q.n_values - Q.n_hot));  // ranks beyond the LDS copy
     const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
     unsigned char* wbase = smem + Q.idx_off + (size_t)wave * (PPL * kE5GroupBytes);
     {
@@ -158,6 +202,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
         __syncthreads();
     }
+    const __amdgpu_buffer_rsrc_t cold_values = values;
 
     uint32_t s = 0, n = 0, p0 = 0;
     uint64_t beg = 0;
@@ -173,7 +218,9 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
     // this lane's two 32-byte columns of every group's index buffer (what it reads, and what it resets) and
     // the entry of its own start position's 1-byte token (what it writes, + 32 bytes per further byte)
     const uint32_t my_col = r * kE5RowStride + ((l - 1u) & 15u) * 32u;
-    const uint32_t wr_off = Q.idx_off + wave * (PPL * kE5GroupBytes) + r * kE5RowStride + l * 2u;  // LDS byte offset, column bits clear
+    const uint32_t wbase_off = lds0 + Q.idx_off + wave * (PPL * kE5GroupBytes);  // this wave's match-index buffers, LDS byte offset
+    const uint32_t wr_off = wbase_off + r * kE5RowStride + l * 2u;                // ... this lane's entries as a walker, column bits clear
+    const uint32_t col_off = wbase_off + my_col;                                  // ... and its 32 contiguous bytes as the relaxing lane
     uint64_t seg[5] = {0, 0, 0, 0, 0};
     uint64_t t_last = P.stamps ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
     uint32_t iters = 0;
@@ -260,7 +307,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             // sample loop, kept in registers and spilled)
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
-            WalkCtx<PPL> W{trie, smem, s, l32, P.dropout, P.seed};
+            WalkCtx<PPL> W{trie_b, s, l32, P.dropout, P.seed};
             Walk5<DROPOUT, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
         }
         __builtin_amdgcn_wave_barrier();
@@ -277,36 +324,75 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
         if (!(P.flags & 32u)) __builtin_amdgcn_s_setprio(0);
         uint32_t fin[PPL];
         bool reached[PPL];
+        if (!(P.flags & 2u)) {
+            // the scores of four steps at a time, requested a quarter group ahead of the steps that use them
+            uint32_t iw[8], iwn[8];
+            auto load_iw = [&](int g, uint32_t (&w)[8]) {
+                const u32x4_t ia = lds_ld<u32x4_t>(col_off + g * kE5GroupBytes), ib = lds_ld<u32x4_t>(col_off + g * kE5GroupBytes + 16u);
+                w[0] = ia.x; w[1] = ia.y; w[2] = ia.z; w[3] = ia.w;
+                w[4] = ib.x; w[5] = ib.y; w[6] = ib.z; w[7] = ib.w;
+            };
+            u32x2_t sa[4], sb[4];
+            load_iw(0, iw);
+            if (!COLD) e5_scores_issue<4>(lds0, iw, 0, sa);
 #pragma unroll
-        for (int g = 0; g < PPL; ++g) {
-            fin[g] = kNoStep;
-            reached[g] = true;
-            if (P.flags & 2u) continue;
-            const uint4* ip = reinterpret_cast<const uint4*>(wbase + g * kE5GroupBytes + my_col);
-            const uint4 ia = ip[0], ib = ip[1];
-            const uint32_t iw[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
-            // the scores of eight steps at a time (all sixteen cost 32 registers: a wave per SIMD)
-            uint32_t fhi = 0xFFF00000u;
-            double sv[8];
-            e5_scores<COLD, 8>(smem, values, iw, 0, hot_bytes, sv);
-            relax5_step<0>(sv[0], acc, bpv, fin[g], fhi);
-            relax5_step<1>(sv[1], acc, bpv, fin[g], fhi);
-            relax5_step<2>(sv[2], acc, bpv, fin[g], fhi);
-            relax5_step<3>(sv[3], acc, bpv, fin[g], fhi);
-            relax5_step<4>(sv[4], acc, bpv, fin[g], fhi);
-            relax5_step<5>(sv[5], acc, bpv, fin[g], fhi);
-            relax5_step<6>(sv[6], acc, bpv, fin[g], fhi);
-            relax5_step<7>(sv[7], acc, bpv, fin[g], fhi);
-            e5_scores<COLD, 8>(smem, values, iw, 8, hot_bytes, sv);
-            relax5_step<8>(sv[0], acc, bpv, fin[g], fhi);
-            relax5_step<9>(sv[1], acc, bpv, fin[g], fhi);
-            relax5_step<10>(sv[2], acc, bpv, fin[g], fhi);
-            relax5_step<11>(sv[3], acc, bpv, fin[g], fhi);
-            relax5_step<12>(sv[4], acc, bpv, fin[g], fhi);
-            relax5_step<13>(sv[5], acc, bpv, fin[g], fhi);
-            relax5_step<14>(sv[6], acc, bpv, fin[g], fhi);
-            relax5_step<15>(sv[7], acc, bpv, fin[g], fhi);
-            reached[g] = fhi != 0xFFF00000u;
+            for (int g = 0; g < PPL; ++g) {
+                uint32_t (&cw)[8] = (g & 1) ? iwn : iw;
+                uint32_t (&nw)[8] = (g & 1) ? iw : iwn;
+                fin[g] = kNoStep;
+                uint32_t fhi = 0xFFF00000u;
+                if (COLD) {
+                    double sv[8];
+                    e5_scores_cold<8>(lds0, cold_values, cw, 0, hot_bytes, sv);
+                    if (g + 1 < PPL) load_iw(g + 1, nw);
+                    relax5_step<0>(sv[0], acc, bpv, fin[g], fhi);
+                    relax5_step<1>(sv[1], acc, bpv, fin[g], fhi);
+                    relax5_step<2>(sv[2], acc, bpv, fin[g], fhi);
+                    relax5_step<3>(sv[3], acc, bpv, fin[g], fhi);
+                    relax5_step<4>(sv[4], acc, bpv, fin[g], fhi);
+                    relax5_step<5>(sv[5], acc, bpv, fin[g], fhi);
+                    relax5_step<6>(sv[6], acc, bpv, fin[g], fhi);
+                    relax5_step<7>(sv[7], acc, bpv, fin[g], fhi);
+                    e5_scores_cold<8>(lds0, cold_values, cw, 8, hot_bytes, sv);
+                    relax5_step<8>(sv[0], acc, bpv, fin[g], fhi);
+                    relax5_step<9>(sv[1], acc, bpv, fin[g], fhi);
+                    relax5_step<10>(sv[2], acc, bpv, fin[g], fhi);
+                    relax5_step<11>(sv[3], acc, bpv, fin[g], fhi);
+                    relax5_step<12>(sv[4], acc, bpv, fin[g], fhi);
+                    relax5_step<13>(sv[5], acc, bpv, fin[g], fhi);
+                    relax5_step<14>(sv[6], acc, bpv, fin[g], fhi);
+                    relax5_step<15>(sv[7], acc, bpv, fin[g], fhi);
+                } else {
+                    e5_scores_issue<4>(lds0, cw, 4, sb);
+                    if (g + 1 < PPL) load_iw(g + 1, nw);
+                    relax5_step<0>(e5_score_value(sa[0]), acc, bpv, fin[g], fhi);
+                    relax5_step<1>(e5_score_value(sa[1]), acc, bpv, fin[g], fhi);
+                    relax5_step<2>(e5_score_value(sa[2]), acc, bpv, fin[g], fhi);
+                    relax5_step<3>(e5_score_value(sa[3]), acc, bpv, fin[g], fhi);
+                    e5_scores_issue<4>(lds0, cw, 8, sa);
+                    relax5_step<4>(e5_score_value(sb[0]), acc, bpv, fin[g], fhi);
+                    relax5_step<5>(e5_score_value(sb[1]), acc, bpv, fin[g], fhi);
+                    relax5_step<6>(e5_score_value(sb[2]), acc, bpv, fin[g], fhi);
+                    relax5_step<7>(e5_score_value(sb[3]), acc, bpv, fin[g], fhi);
+                    e5_scores_issue<4>(lds0, cw, 12, sb);
+                    relax5_step<8>(e5_score_value(sa[0]), acc, bpv, fin[g], fhi);
+                    relax5_step<9>(e5_score_value(sa[1]), acc, bpv, fin[g], fhi);
+                    relax5_step<10>(e5_score_value(sa[2]), acc, bpv, fin[g], fhi);
+                    relax5_step<11>(e5_score_value(sa[3]), acc, bpv, fin[g], fhi);
+                    if (g + 1 < PPL) e5_scores_issue<4>(lds0, nw, 0, sa);
+                    relax5_step<12>(e5_score_value(sb[0]), acc, bpv, fin[g], fhi);
+                    relax5_step<13>(e5_score_value(sb[1]), acc, bpv, fin[g], fhi);
+                    relax5_step<14>(e5_score_value(sb[2]), acc, bpv, fin[g], fhi);
+                    relax5_step<15>(e5_score_value(sb[3]), acc, bpv, fin[g], fhi);
+                }
+                reached[g] = fhi != 0xFFF00000u;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < PPL; ++g) {
+                fin[g] = kNoStep;
+                reached[g] = true;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (!(P.flags & 32u)) __builtin_amdgcn_s_setprio(2);
@@ -392,9 +478,16 @@ __device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) { __hip_atomi
 
 // the four score values of a quarter group (steps 4 q .. 4 q + 3) of a lane: 16-bit ranks in iw
 template <bool COLD>
-__device__ __forceinline__ void e6_load_quarter(const unsigned char* smem, const unsigned char* __restrict__ values, uint32_t hot_bytes,
+__device__ __forceinline__ void e6_load_quarter(uint32_t tab, __amdgpu_buffer_rsrc_t cold, uint32_t hot_bytes,
                                                 const uint32_t (&iw)[8], int q, double (&sv)[4]) {
-    e5_scores<COLD, 4>(smem, values, iw, 4 * q, hot_bytes, sv);
+    if (COLD) {
+        e5_scores_cold<4>(tab, cold, iw, 4 * q, hot_bytes, sv);
+    } else {
+        u32x2_t sp[4];
+        e5_scores_issue<4>(tab, iw, 4 * q, sp);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sv[u] = e5_score_value(sp[u]);
+    }
 }
 
 template <bool DROPOUT, bool COLD>
@@ -406,9 +499,11 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
     const uint32_t l = lane & 15u, r = lane >> 4;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint2* __restrict__ trie = reinterpret_cast<const uint2*>(Q.trie8);
+    const __amdgpu_buffer_rsrc_t trie_b = make_rsrc(Q.trie8, Q.trie_bytes);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);  // LDS byte offset of the dynamic LDS (0 here)
     double* const score_tab = reinterpret_cast<double*>(smem);
     const uint32_t hot_bytes = 8u * (Q.n_hot + 1u);
-    const unsigned char* __restrict__ values = reinterpret_cast<const unsigned char*>(Q.values);
+    const __amdgpu_buffer_rsrc_t values = make_rsrc(reinterpret_cast<const unsigned char*>(Q.values) + hot_bytes, 8u * (Q.n_values - Q.n_hot));  // ranks beyond the LDS copy
     const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
     E6Ctrl* const ctrl_all = reinterpret_cast<E6Ctrl*>(smem + Q.ctrl_off);
     {
@@ -498,30 +593,30 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
             uint32_t iwa[8], iwb[8];
             double sva[4], svb[4];
             load_iw(0, iwa);
-            e6_load_quarter<COLD>(smem, values, hot_bytes, iwa, 0, sva);
+            e6_load_quarter<COLD>(lds0, values, hot_bytes, iwa, 0, sva);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint32_t (&iw)[8] = (g & 1) ? iwb : iwa;
                 uint32_t (&iwn)[8] = (g & 1) ? iwa : iwb;
                 fin[g] = kNoStep;
                 uint32_t fhi = 0xFFF00000u;
-                e6_load_quarter<COLD>(smem, values, hot_bytes, iw, 1, svb);
+                e6_load_quarter<COLD>(lds0, values, hot_bytes, iw, 1, svb);
                 if (g < 3) load_iw(g + 1, iwn);
                 relax5_step<0>(sva[0], acc, bpv, fin[g], fhi);
                 relax5_step<1>(sva[1], acc, bpv, fin[g], fhi);
                 relax5_step<2>(sva[2], acc, bpv, fin[g], fhi);
                 relax5_step<3>(sva[3], acc, bpv, fin[g], fhi);
-                e6_load_quarter<COLD>(smem, values, hot_bytes, iw, 2, sva);
+                e6_load_quarter<COLD>(lds0, values, hot_bytes, iw, 2, sva);
                 relax5_step<4>(svb[0], acc, bpv, fin[g], fhi);
                 relax5_step<5>(svb[1], acc, bpv, fin[g], fhi);
                 relax5_step<6>(svb[2], acc, bpv, fin[g], fhi);
                 relax5_step<7>(svb[3], acc, bpv, fin[g], fhi);
-                e6_load_quarter<COLD>(smem, values, hot_bytes, iw, 3, svb);
+                e6_load_quarter<COLD>(lds0, values, hot_bytes, iw, 3, svb);
                 relax5_step<8>(sva[0], acc, bpv, fin[g], fhi);
                 relax5_step<9>(sva[1], acc, bpv, fin[g], fhi);
                 relax5_step<10>(sva[2], acc, bpv, fin[g], fhi);
                 relax5_step<11>(sva[3], acc, bpv, fin[g], fhi);
-                if (g < 3) e6_load_quarter<COLD>(smem, values, hot_bytes, iwn, 0, sva);
+                if (g < 3) e6_load_quarter<COLD>(lds0, values, hot_bytes, iwn, 0, sva);
                 relax5_step<12>(svb[0], acc, bpv, fin[g], fhi);
                 relax5_step<13>(svb[1], acc, bpv, fin[g], fhi);
                 relax5_step<14>(svb[2], acc, bpv, fin[g], fhi);
@@ -616,12 +711,12 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
             const uint32_t rem = pgl < n ? (n - pgl) : 0u;
             maxd[0] = rem < LM ? rem : LM;
             alive[0] = maxd[0] > 0;
-            wlane[0] = slot_off + r * kE5RowStride + l * 2u;
+            wlane[0] = lds0 + slot_off + r * kE5RowStride + l * 2u;
             c[0] = bytes[0][0] & 0xFFu;
             rec[0] = rootc[(Q.root_base ^ c[0]) & 255u];
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
-            WalkCtx<1> W{trie, smem, s, l32, P.dropout, P.seed};
+            WalkCtx<1> W{trie_b, s, l32, P.dropout, P.seed};
             Walk5<DROPOUT, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0u) lds_store(&ctrl->walk_done[slot], t + 1u);
@@ -641,7 +736,7 @@ static encode5_fn pick_encode5(bool dropout, bool cold, int ppl) {
     return dropout ? encode5_kernel<true, false, 4> : encode5_kernel<false, false, 4>;
 }
 
-// LDS of one block of `waves` waves: score table (n_hot + 1 values), root records, match indices
+// LDS of one block of `waves` waves: score table (-inf and n_hot values), root records, match indices
 uint32_t encode5_lds_layout(uint32_t n_hot, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off) {
     const uint32_t score_bytes = 8u * (n_hot + 1u);
     const uint32_t ro = (score_bytes + 15u) & ~15u;

@@ -36,6 +36,7 @@ struct EncodeParams {
 // encode5_kernel / encode6_kernel (encode5.hip): 8-byte label-checked records, score values by rank
 struct Encode5Params {
     const void* trie8;              // Trie8Rec[n_slots]
+    uint32_t trie_bytes;            // 8 * n_slots
     const double* values;           // f64[n_values + 1]: values[0] = -inf, values[r] = the score value of rank r
     uint32_t root_base;
     uint32_t n_values;              // distinct score values of the vocabulary (<= 65 535)

@@ -167,10 +167,6 @@ struct KernelTime {
     bool used;
 };
 constexpr int kMaxTimed = 8;
-// encode5_kernel with a vocabulary whose score values do not all fit the block's LDS beside sixteen waves of
-// match indices (COLD builds): waves per block, which fixes the size of the LDS copy of the value table
-// (encode5_max_hot: 14 waves leave room for ~5 700 values, 12 for ~7 800, 16 for ~3 700)
-constexpr int kE5ColdWaves = 14;
 
 }  // namespace
 
@@ -385,20 +381,30 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? (use5 ? "rows5" : "rows4") : (use2 ? "rows2" : "fused"),
                 m->flat.table.size(), p.root_base, m->n_values);
     if (use5) {
-        // Four positions per lane and iteration: the four walks of a lane are staggered (encode5.hip: Walk5), so
-        // more of them hide more of each other's gather latency, and four was the fastest on every corpus shape
-        // measured (profiles/r02: 1 GiB of samples <= 64 KiB / 4 KiB / 1 KiB, 256 MiB of samples <= 256 B, and the
-        // serial chain of a single 64 KiB sample).  One block of sixteen waves per CU (87 registers: five waves
-        // per SIMD would fit, the 8 KiB of match indices per wave do not).  The block's LDS holds a copy of the
-        // first n_hot score values: all of them when they fit beside sixteen waves (no COLD code in the kernel),
-        // otherwise what kE5ColdWaves waves leave room for; fewer waves when the batch has fewer samples than
-        // the chip has rows, so that they spread over the CUs.
-        int ppl = 4;
+        // One block of sixteen waves per CU, and the block's LDS (160 KiB) is shared by the match-index buffers (2 KiB
+        // per wave and 16 positions per lane) and the copy of the hottest score values.  Three geometries, by the
+        // number of distinct score values (1 GiB of the bench corpus, profiles/r03):
+        //   * four positions per lane (the four staggered walks of a lane hide most of each other's gather latency,
+        //     encode5.hip: Walk5) with EVERY value in LDS: up to ~3 700 values, 11.0 ms;
+        //   * two positions per lane, every value in LDS: up to ~11 900 values — the generate-style vocabularies
+        //     of SURVEY.md 8(d), 9 652 values at 32 000 entries, 10 569 at 65 536 —, 12.7 ms;
+        //   * four positions per lane with the ~3 700 hottest values in LDS and the others read from L2 by the
+        //     relaxing lanes (COLD builds; every token its own score: after an M-step or merge), 14.2 - 14.6 ms.
+        // Fewer waves when the batch has fewer samples than the chip has rows, so that they spread over the CUs.
+        int ppl = 4, bpc = 1;
+        {
+            int ps4 = 0;
+            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, 4, &ps4));
+            const int w4 = std::min(16, ps4 * 4);
+            if (m->n_values > tgx::encode5_max_hot(w4, 4, 160u * 1024u) && m->n_values <= tgx::encode5_max_hot(16, 2, 160u * 1024u)) ppl = 2;
+        }
         if (const char* e = knob("TGX_PPL")) {
             const int v = atoi(e);
-            if (v == 1 || v == 2 || v == 4) ppl = v;
+            if (v == 1 || v == 2 || v == 4) {
+                ppl = v;
+                bpc = ppl == 4 ? 1 : 2;
+            }
         }
-        int bpc = ppl == 4 ? 1 : 2;
         if (const char* e = knob("TGX_BPC")) {
             const int v = atoi(e);
             if (v >= 1 && v <= 8) bpc = v;
@@ -411,7 +417,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         if (m->n_values > tgx::encode5_max_hot(waves, ppl, budget)) {
             cold = true;
             HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, true, ppl, &per_simd));
-            waves = std::min(std::min(16, (per_simd / bpc) * 4), ppl == 4 ? kE5ColdWaves : 16);
+            waves = std::min(16, (per_simd / bpc) * 4);
         }
         {
             const uint64_t rows_wanted = (c->n_samples + (uint64_t)m->num_cus * bpc - 1) / ((uint64_t)m->num_cus * bpc);
@@ -436,6 +442,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
         tgx::Encode5Params q{};
         q.trie8 = m->d_trie8;
+        q.trie_bytes = (uint32_t)(m->flat.table.size() * sizeof(tgx::Trie8Rec));
         q.values = m->d_values;
         q.root_base = m->root_base8;
         q.n_values = m->n_values;
@@ -792,7 +799,7 @@ static tgx_status ensure_encode_tables(tgx_model* m) {
     // the bytes -> id table and the 8-byte records are independent: the first is built on a second host thread
     // while this one builds the second (each ~50 ms at 500 000 tokens)
     const bool want_hash = m->lm <= 32 && m->scores_finite;
-    const bool want_trie8 = m->lm <= 16 && m->scores_finite && m->flat.table.size() < (1u << 24);
+    const bool want_trie8 = m->lm <= 16 && m->scores_finite && m->flat.table.size() <= tgx::kTrie8MaxSlots;
     std::thread hash_builder;
     if (want_hash && !m->tokhash_host_built)
         hash_builder = std::thread([m]() { tgx::build_tok_hash(m->vocab_bytes.data(), m->vocab_offs.data(), m->vocab_size, &m->tokhash); });
@@ -1026,7 +1033,7 @@ uint64_t tgx_flat_trie_search8(const tgx_flat_trie* t, const uint8_t* bytes, con
     }
     const tgx::Trie8& t8 = *tm->t8;
     (void)bytes;
-    if (!t8.ok) return ~0ULL;  // more than 65 535 distinct score values (or too many slots): no 8-byte records
+    if (!t8.ok) return ~0ULL;  // more than 65 535 distinct score values (or more than 2^21 slots): no 8-byte records
     const uint32_t n_values = (uint32_t)t8.values.size() - 1u, k = std::min(max_hot, n_values);
     if (n_hot) *n_hot = k;
     if (n_cold) {

@@ -295,7 +295,7 @@ void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores,
         total_w += w;
         val_of[i] = (uint32_t)vals.size() - 1;
     }
-    if (vals.size() > kTrie8MaxValues || n_slots >= (1u << 24)) return;  // ranks are 16 bits, bases 24
+    if (vals.size() > kTrie8MaxValues || n_slots > kTrie8MaxSlots) return;  // ranks are 16 bits, 8 * base 24
     std::vector<uint32_t> order(vals.size());
     for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
@@ -320,44 +320,32 @@ void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores,
     out->coverage.back() = 1.0;  // all values (the running sum need not end exactly on the total)
     std::vector<uint32_t> sref(n_slots, 0);
     for (size_t i = 0; i < by_bits.size(); i++) sref[by_bits[i].second] = rank[val_of[i]];
-    // child masks: the parent of a used slot t is ft.table[t].check, its edge byte ft.label[t]
-    uint32_t root_mask = 0;
-    for (uint32_t t = 1; t < n_slots; t++) {
-        if (ft.table[t].check == kNoParent) continue;
-        const uint32_t parent = ft.table[t].check, bit = 1u << ((uint32_t)ft.label[t] >> 4);
-        if (parent == 0u) root_mask |= bit;
-        else sref[parent] |= bit << 16;
-    }
     for (uint32_t t = 0; t < n_slots; t++) {
         Trie8Rec& q = out->rec[t];
         const bool used = t != 0 && ft.table[t].check != kNoParent;
         if (used) {
             const uint32_t base = ft.inner[t] ? (ft.table[t].base & ~kTerminalBit) : kTrie8LeafBase;
-            q.rec = (uint32_t)ft.label[t] | (base << 8);
+            q.rec = (base << 3) | ((uint32_t)ft.label[t] << 24);
             q.sref = sref[t];
         } else {  // unused slots (and the root's own slot) can never pass the label check: see BlockAlloc::add_block
-            q.rec = ((t ^ 0xFFu) & 0xFFu) | (kTrie8LeafBase << 8);
+            q.rec = (kTrie8LeafBase << 3) | (((t ^ 0xFFu) & 0xFFu) << 24);
             q.sref = 0;
         }
     }
     out->root_base = ft.inner[0] ? (ft.table[0].base & ~kTerminalBit) : kTrie8LeafBase;
-    out->root_mask = root_mask;
     out->ok = true;
 }
 
-// host twin of the device walk over the 8-byte records, child masks included
+// host twin of the device walk over the 8-byte records
 uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const uint8_t* s, uint64_t n, uint32_t* ids,
                                     uint32_t* lens, uint64_t cap) {
-    uint32_t base = t8.root_base, mask = t8.root_mask;
+    uint32_t off = (t8.root_base ^ (n ? s[0] : 0u)) << 3;  // byte offset of the record to read
     uint64_t found = 0;
     for (uint64_t i = 0; i < n; i++) {
-        if (!((mask >> (s[i] >> 4)) & 1u)) break;  // no child in this byte's class: the walk ends without a probe
-        const uint32_t t = base ^ s[i];
+        const uint32_t t = off >> 3;
         if (t >= t8.rec.size()) break;
         const uint32_t r = t8.rec[t].rec;
-        if ((r & 0xFFu) != s[i]) break;
-        base = r >> 8;
-        mask = t8.rec[t].sref >> 16;
+        if ((r >> 24) != s[i]) break;
         if (t8.rec[t].sref & kTrie8RankMask) {
             if (found < cap) {
                 ids[found] = ft.tokid[t];
@@ -365,6 +353,7 @@ uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const u
             }
             found++;
         }
+        if (i + 1 < n) off = (r ^ ((uint32_t)s[i + 1] << 3)) & 0xFFFFFFu;
     }
     return found;
 }

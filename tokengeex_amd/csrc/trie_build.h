@@ -44,33 +44,38 @@ struct FlatTrie {
 void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                      uint32_t vocab_size, FlatTrie* out);
 
-// Label-checked 8-byte records over the SAME slot assignment (encode5_kernel): the walk keeps only `base`,
-//   t = base ^ byte;  {rec, sref} = table[t];  valid iff (rec & 0xFF) == byte;  base = rec >> 8
-// which is exact because build_flat_trie gives every node with children a base of its own (if slot t passes
-// the check for (base, byte) its owner's base is t ^ byte = base) whose low byte is neither 0xFE nor 0xFF:
-// leaves point at base 0xFE of block 0 (the root's block, otherwise empty) and an unused slot t carries the
-// label (t ^ 0xFF) & 0xFF, so neither can pass.
-// `sref` (round 3): bits 0..15 = RANK of the token's score value, 0 for a slot no token ends at — the distinct
-// score values of the vocabulary are ranked by how often their tokens are expected to match (1 = hottest), and
-// `values[rank]` is the table the kernels read: its first entries from a copy in LDS, the rest from HBM / L2.
-// A vocabulary after an M-step has one value per token (src/prune.rs:143-151), so ranks must cover 65 535 values;
-// a vocabulary with more distinct values than that has no Trie8 (ok == false: the 16-byte records serve it).
-// bits 16..31 = CHILD MASK: bit (c >> 4) is set iff the node has a child whose edge byte c' has c' >> 4 == c >> 4.
-// A walk whose next text byte has its bit clear ends without a gather: 3.46 -> 2.55 gathers per position below
-// the root level on the bench corpus (a leaf has mask 0; 87 % of the failing probes are gone).
+// Label-checked 8-byte records over the SAME slot assignment (encode5_kernel): the walk keeps only the record,
+//   rec = table[off / 8];  valid iff (rec >> 24) == byte;  next off = (rec ^ (next byte << 3)) & 0xFFFFFF
+// i.e. `rec` = 8 * base (the BYTE offset of the node's child block: (base ^ c) * 8 = 8 base ^ 8 c) in its low 24
+// bits and the label — the byte of the edge that leads to the slot — in its top byte: one compare, one shift of
+// the text byte and one three-input bit operation per step (round 3; the first layout, label | base << 8, took
+// four instructions for the address alone, and the kernel is bound by vector-instruction issue).  Exact because
+// build_flat_trie gives every node with children a base of its own (if slot t passes the check for (base, byte) its
+// owner's base is t ^ byte = base) whose low byte is neither 0xFE nor 0xFF: leaves point at base 0xFE of block 0
+// (the root's block, otherwise empty) and an unused slot t carries the label (t ^ 0xFF) & 0xFF, so neither can
+// pass.  8 base < 2^24 limits the table to 2^21 slots (a 65 536-entry vocabulary has ~3 * 10^5).
+// `sref`: the RANK of the token's score value, 0 for a slot no token ends at — the distinct score values of the
+// vocabulary are ranked by how often their tokens are expected to match (1 = hottest), and `values[rank]` is the
+// table the kernels read: its first entries from a copy in LDS, the rest from HBM / L2.  A vocabulary after an
+// M-step has one value per token (src/prune.rs:143-151), so ranks must cover 65 535 values; a vocabulary with more
+// distinct values than that has no Trie8 (ok == false: the 16-byte records serve it).
+// (Round 3 also tried a 16-bit CHILD MASK in the upper half of sref — bit (c >> 4) set iff the node has a child
+// in that byte class — which ends 87 % of the walks' failing probes without a gather (3.46 -> 2.55 gathers per
+// position below the root level): the kernel got 4 % SLOWER, the five instructions of the test cost more than the
+// gathers they save — DESIGN.md section 6.)
 struct Trie8Rec {
-    uint32_t rec;   // label | base << 8
-    uint32_t sref;  // rank | child mask << 16
+    uint32_t rec;   // 8 * base | label << 24
+    uint32_t sref;  // rank of the score value (16 bits), 0: no token ends here
 };
 constexpr uint32_t kTrie8RankMask = 0xFFFFu;
 constexpr uint32_t kTrie8MaxValues = 65535u;
+constexpr uint32_t kTrie8MaxSlots = 1u << 21;
 constexpr uint32_t kTrie8LeafBase = 0xFEu;
 struct Trie8 {
     std::vector<Trie8Rec> rec;     // n_slots
     std::vector<uint64_t> values;  // bit patterns: values[0] = -inf ("no token"), values[r] = the value of rank r
     std::vector<double> coverage;  // coverage[k] = expected share of the matches whose value has rank <= k (k = 0 .. n)
     uint32_t root_base = 0;
-    uint32_t root_mask = 0;        // child mask of the root (bits 0..15)
     bool ok = false;
 };
 void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores, Trie8* out);

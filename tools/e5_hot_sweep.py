@@ -20,11 +20,12 @@ for vname in vocabs:
         scores = scores + np.random.default_rng(5).uniform(-0.4, 0.4, len(toks))
     m = tgx.NativeModel(toks, scores)
     print(f"== {vname}: {len(toks)} tokens, {np.unique(scores).size} distinct values, {size} MiB", flush=True)
-    cfgs = [dict(TGX_PATH="rows4")] + [dict(TGX_WAVES=str(w)) for w in (16, 15, 14, 13, 12, 11, 10)] + \
-           [dict(TGX_WAVES="16", TGX_E5_HOT=h) for h in ("2047", "1023", "0")] + [dict(TGX_WAVES="14", TGX_E5_HOT="4095")] + \
-           [dict(TGX_WAVES="16", TGX_PPL="2"), dict(TGX_WAVES="16", TGX_PPL="2", TGX_E5_HOT="8191"), dict(TGX_WAVES="12", TGX_PPL="2", TGX_BPC="2")]
+    cfgs = [dict(TGX_WAVES=str(w)) for w in (16, 15, 14)] + \
+           [dict(TGX_WAVES="16", TGX_E5_POOL=p) for p in ("24", "32", "64")] + \
+           [dict(TGX_WAVES="16", TGX_E5_HOT=h) for h in ("2047", "0")] + \
+           [dict(TGX_WAVES="16", TGX_PPL="2", TGX_BPC="1")]
     for cfg in cfgs:
-        for k in ("TGX_PATH", "TGX_WAVES", "TGX_E5_HOT", "TGX_PPL", "TGX_BPC"):
+        for k in ("TGX_PATH", "TGX_WAVES", "TGX_E5_HOT", "TGX_E5_POOL", "TGX_PPL", "TGX_BPC"):
             os.environ.pop(k, None)
         os.environ.update(cfg)
         os.environ.setdefault("TGX_LONG_THRESHOLD", "0")
