@@ -129,6 +129,17 @@ tgx_status tgx_substring_df(int device, const uint8_t *text, uint64_t n_bytes, c
                             uint32_t max_token_length, double insert_probability, uint64_t seed,
                             uint64_t **out_pos, uint32_t **out_len, uint32_t **out_df, uint64_t *n_out,
                             uint64_t *n_windows, uint64_t *n_collisions);
+/* The same with only the top_k most frequent substrings leaving the device, in descending frequency (top_k = 0:
+ * all): VocabularyGenerator::generate keeps the most frequent substrings (src/generate.rs:150-152, 199-213), and
+ * copying every distinct substring of a corpus to the host (254 M for 64 MiB of text) is what bounded `feed`.
+ * *n_distinct = distinct substrings counted; *cutoff_df = the frequency of the most frequent substring NOT
+ * returned (0 when nothing was cut): whatever is missing from the output occurs in at most that many samples. */
+tgx_status tgx_substring_df_top(int device, const uint8_t *text, uint64_t n_bytes, const uint64_t *part_begin,
+                                const uint64_t *part_end, const uint32_t *part_sample, uint64_t n_parts,
+                                uint32_t max_token_length, double insert_probability, uint64_t seed,
+                                uint64_t top_k, uint64_t **out_pos, uint32_t **out_len, uint32_t **out_df,
+                                uint64_t *n_out, uint64_t *n_windows, uint64_t *n_collisions,
+                                uint64_t *n_distinct, uint32_t *cutoff_df);
 double tgx_generate_u01(uint64_t seed, uint64_t sample, uint64_t window_hash);
 
 /* ---- host-only trie introspection (no device needed) ------------------------

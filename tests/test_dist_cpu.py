@@ -104,3 +104,46 @@ def test_two_rank_pair_table_merge(tmp_path):
         np.testing.assert_array_equal(p["k"], wk)
         np.testing.assert_array_equal(p["c"], wc)
         assert int(p["n"]) == offs.size - 1
+
+
+def _top_pairs_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        flat, offs = synth.make_corpus(256 << 10, "mixed")
+        toks, scores = synth.build_vocab(flat, 800, 12)
+        lo, hi = tdist.shard_bounds(offs, world)[rank]
+        sflat, soffs = tdist.take_shard(flat, offs, lo, hi)
+        keys, counts = orc.OracleModel(toks, scores).count_pairs_flat(sflat, soffs)  # stands in for the GPU scan
+        out = {}
+        for k in (64, 1000, 10 ** 7):
+            ck, cc, bound, nbytes = tdist.top_pairs_exchange(keys, counts, k, dist)
+            out[f"k{k}"], out[f"c{k}"], out[f"b{k}"], out[f"n{k}"] = ck, cc, bound, nbytes
+        np.savez(os.path.join(out_dir, f"t{rank}.npz"), local=keys.size, **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_top_pairs_exchange(tmp_path):
+    """dist.top_pairs_exchange (what `merge` exchanges per round with several ranks): every candidate's count is its
+    exact global count, every pair whose global count exceeds the bound is among the candidates — the head of the
+    single-process table, identical on both ranks — and the bytes exchanged are a small fraction of the tables."""
+    world, port = 2, _free_port()
+    mp.spawn(_top_pairs_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    t0, t1 = np.load(tmp_path / "t0.npz"), np.load(tmp_path / "t1.npz")
+    flat, offs = synth.make_corpus(256 << 10, "mixed")
+    toks, scores = synth.build_vocab(flat, 800, 12)
+    wk, wc = orc.OracleModel(toks, scores).count_pairs_flat(flat, offs)
+    truth = dict(zip(wk.tolist(), wc.tolist()))
+    for k in (64, 1000, 10 ** 7):
+        ck, cc, bound = t0[f"k{k}"], t0[f"c{k}"], int(t0[f"b{k}"])
+        np.testing.assert_array_equal(ck, t1[f"k{k}"])
+        np.testing.assert_array_equal(cc, t1[f"c{k}"])
+        assert all(truth[int(a)] == int(b) for a, b in zip(ck, cc))                     # exact global counts
+        head = {int(a) for a, c in truth.items() if c > bound}
+        assert head <= set(ck.tolist())                                                  # nothing above the bound is missing
+        if k == 64:
+            assert 0 < bound and 10 < len(head) < wk.size and int(t0["n64"]) < 16 * int(t0["local"]) // 10
+        if k == 10 ** 7:
+            assert bound == 0 and ck.size == wk.size                                     # whole tables: the whole result

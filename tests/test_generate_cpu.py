@@ -1,13 +1,15 @@
-"""VocabularyGenerator (src/generate.rs) through its host restatement (device=None: the checker of the device path,
-tests/test_generate_gpu.py): the reference's own test case plus the invariants of generate()."""
+"""The oracle's restatement of VocabularyGenerator (oracle/generate_oracle.py, src/generate.rs:12-243) — the checker
+of the device path (tests/test_generate_gpu.py) — pinned by the reference's own test case (src/generate.rs:258-284)
+and by hand-checkable document frequencies; plus the invariants of generate()."""
 import math
+import re
 
-from tokengeex_amd.generate import VocabularyGenerator
+from oracle.generate_oracle import OracleVocabularyGenerator, fnv1a64, keep_u01
 
 
 def _reference_case():
     # src/generate.rs:258-276 (test_generate)
-    g = VocabularyGenerator(6, 1.0, None, r"^ ?[a-z]+$", ["goodbye", "vec"], ["string", "map"], device=None)
+    g = OracleVocabularyGenerator(6, 1.0, None, re.compile(r"^ ?[a-z]+$"), ["goodbye", "vec"], ["string", "map"])
     g.feed(["hello my name is diego and i like std::string", "i also like std::vector",
             "and std::vector<std::string>", "and std::map<int, std::string>"])
     return g
@@ -25,27 +27,29 @@ def test_reference_generate_case():
     assert all(t[2] for t in vocab if len(t[0]) == 1)
     assert abs(sum(math.exp(t[1]) for t in vocab) - 1.0) < 1e-12  # log-probabilities
     assert all(vocab[i][1] >= vocab[i + 1][1] for i in range(len(vocab) - 1))
+    # document frequencies by hand: "string" is in samples 0, 2, 3 (+ 1 from the constructor); " like" in 0 and 1
+    assert g.frequencies["string"] == 4 and g.frequencies[" like"] == 2 and g.frequencies["vec"] == 3
+    assert "std" in g.frequencies and "::" not in g.frequencies   # the allow pattern
 
 
 def test_document_frequencies_and_limits():
-    g = VocabularyGenerator(4, 1.0, None, None, device=None)
+    g = OracleVocabularyGenerator(4, 1.0, None, None)
     g.feed(["abab", "ab", "xyz"])
     assert g.frequencies["ab"] == 2 and g.frequencies["abab"] == 1 and g.frequencies["b"] == 2   # once per sample
     assert "ababa" not in g.frequencies and max(len(k.encode()) for k in g.frequencies) <= 4
-    g2 = VocabularyGenerator(4, 1.0, None, None, device=None)
+    g2 = OracleVocabularyGenerator(4, 1.0, None, None)
     g2.feed(["中文中"])                                                                           # 3-byte chars
     assert set(g2.frequencies) == {"中", "文"}                                                   # 6 bytes > 4: no pairs
     # insert_probability: reproducible, monotone in p
-    a = VocabularyGenerator(8, 0.3, None, None, seed=7, device=None); a.feed(["the quick brown fox"] * 3)
-    b = VocabularyGenerator(8, 0.3, None, None, seed=7, device=None); b.feed(["the quick brown fox"] * 3)
-    c = VocabularyGenerator(8, 1.0, None, None, seed=7, device=None); c.feed(["the quick brown fox"] * 3)
+    a = OracleVocabularyGenerator(8, 0.3, None, None, seed=7); a.feed(["the quick brown fox"] * 3)
+    b = OracleVocabularyGenerator(8, 0.3, None, None, seed=7); b.feed(["the quick brown fox"] * 3)
+    c = OracleVocabularyGenerator(8, 1.0, None, None, seed=7); c.feed(["the quick brown fox"] * 3)
     assert a.frequencies == b.frequencies and 0 < len(a.frequencies) < len(c.frequencies)
 
 
 def test_keep_rule_is_the_librarys():
-    """The seeded stand-in for the reference's thread RNG is one function on the host and on the device."""
+    """The seeded stand-in for the reference's thread RNG is one function in the oracle and in the library."""
     from tokengeex_amd import _lib
-    from tokengeex_amd.generate import _fnv1a64, _u01
-    assert _fnv1a64(b"") == 0xCBF29CE484222325 and _fnv1a64(b"a") == 0xAF63DC4C8601EC8C   # FNV-1a test vectors
+    assert fnv1a64(b"") == 0xCBF29CE484222325 and fnv1a64(b"a") == 0xAF63DC4C8601EC8C   # FNV-1a test vectors
     for seed, sample, tok in [(0, 0, "a"), (7, 123456, "hello"), (2**63 + 5, 99, "中文"), (1, 2**26, " x")]:
-        assert _u01(seed, sample, tok) == _lib.generate_u01(seed, sample, _fnv1a64(tok.encode()))
+        assert keep_u01(seed, sample, tok) == _lib.generate_u01(seed, sample, fnv1a64(tok.encode()))

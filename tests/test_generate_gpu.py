@@ -1,7 +1,8 @@
-"""VocabularyGenerator::feed on the device (csrc/generate.hip: tgx_substring_df) against the per-sample host
-restatement of src/generate.rs:54-139 (device=None): identical document frequencies — with and without a split
-regex, an allow regex, added / suggested tokens, insert_probability < 1, multi-byte characters, several feed
-calls — and identical generate() output up to the order of equal scores."""
+"""VocabularyGenerator::feed / generate on the device path (tokengeex_amd/generate.py over csrc/generate.hip:
+tgx_substring_df[_top]) against the oracle's restatement of src/generate.rs:54-243 (oracle/generate_oracle.py):
+identical document frequencies — with and without a split regex, an allow regex, added / suggested tokens,
+insert_probability < 1, multi-byte characters, several feed calls — and identical generate() output, also when only
+the top_k most frequent substrings leave the device."""
 import re
 
 import numpy as np
@@ -9,10 +10,12 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+import tokengeex_amd as tgx
+from oracle.generate_oracle import OracleVocabularyGenerator
 from tokengeex_amd import _lib, synth
 from tokengeex_amd.generate import VocabularyGenerator
-
 from test_merge_cpu import ALLOW
+from util import AllowByHand
 
 
 def _samples(n_bytes, kind="mixed", max_len=1500, seed_offset=0):
@@ -21,36 +24,63 @@ def _samples(n_bytes, kind="mixed", max_len=1500, seed_offset=0):
     return [flat[o[i]:o[i + 1]].tobytes().decode("utf-8") for i in range(o.size - 1)]
 
 
-def _both(samples, *args, chunks=1, **kw):
-    dev, host = VocabularyGenerator(*args, device=0, **kw), VocabularyGenerator(*args, device=None, **kw)
+def _both(samples, mtl, p, split, allow, added=(), suggested=(), chunks=1, seed=0, top_k=None):
+    # the checker's allow pattern never goes through the product's translation: ALLOW is evaluated by hand, the
+    # reference's own test pattern by Python's re (plain syntax, `$` made explicit)
+    pat = AllowByHand() if allow == ALLOW else (re.compile(allow.replace('$', r'\Z')) if isinstance(allow, str) else allow)
+    dev = VocabularyGenerator(mtl, p, split, allow, added, suggested, seed=seed, top_k=top_k)
+    ora = OracleVocabularyGenerator(mtl, p, split, pat, added, suggested, seed=seed)
     step = (len(samples) + chunks - 1) // chunks
     for a in range(0, len(samples), step):
         dev.feed(samples[a:a + step])
-        host.feed(samples[a:a + step])
-    return dev, host
+        ora.feed(samples[a:a + step])
+    return dev, ora
 
 
 def test_reference_case_on_the_device():
     # src/generate.rs:258-276 (test_generate)
-    dev, host = _both(["hello my name is diego and i like std::string", "i also like std::vector",
-                       "and std::vector<std::string>", "and std::map<int, std::string>"],
-                      6, 1.0, None, r"^ ?[a-z]+$", ["goodbye", "vec"], ["string", "map"])
-    assert dev.frequencies == host.frequencies
-    assert any(t[0] == b"string" for t in dev.generate(266))
+    dev, ora = _both(["hello my name is diego and i like std::string", "i also like std::vector",
+                      "and std::vector<std::string>", "and std::map<int, std::string>"],
+                     6, 1.0, None, r"^ ?[a-z]+$", ["goodbye", "vec"], ["string", "map"])
+    assert dev.frequencies == ora.frequencies
+    assert any(t[0] == b"string" for t in dev.generate(266)) and dev.generate(266) == ora.generate(266)
 
 
-def test_document_frequencies_equal_the_host_restatement():
+def test_document_frequencies_equal_the_oracle():
     samples = _samples(160 << 10) + ["", "a", "中文中文", "é" * 9, "x" * 40, "\n\n    return", "𝒳𝒴 math"]
-    dev, host = _both(samples, 16, 1.0, None, None)
-    assert dev.frequencies == host.frequencies and len(dev.frequencies) > 50000
-    dev, host = _both(samples, 12, 1.0, None, ALLOW, chunks=3)                    # allow regex, three feed calls
-    assert dev.frequencies == host.frequencies
+    dev, ora = _both(samples, 16, 1.0, None, None)
+    assert dev.frequencies == ora.frequencies and len(dev.frequencies) > 50000
+    dev, ora = _both(samples, 12, 1.0, None, ALLOW, chunks=3)                     # allow regex, three feed calls
+    assert dev.frequencies == ora.frequencies
     split = re.compile(r"[A-Za-z_]+|[0-9]+|\s+|[^\sA-Za-z_0-9]+")
-    dev, host = _both(samples, 8, 1.0, split, None, ["std::", "return"], ["    ", "中文"])
-    assert dev.frequencies == host.frequencies                                     # split parts + added / suggested
-    dev, host = _both(samples, 10, 0.05, None, None, ["def"], [], chunks=2, seed=11)
-    assert dev.frequencies == host.frequencies and 0 < len(dev.frequencies)        # the seeded keep rule
-    assert dev.generate(3000) == host.generate(3000)                                # same tokens, scores, order
+    dev, ora = _both(samples, 8, 1.0, split, None, ["std::", "return"], ["    ", "中文"])
+    assert dev.frequencies == ora.frequencies                                      # split parts + added / suggested
+    dev, ora = _both(samples, 10, 0.05, None, None, ["def"], [], chunks=2, seed=11)
+    assert dev.frequencies == ora.frequencies and 0 < len(dev.frequencies)         # the seeded keep rule
+    assert dev.generate(3000) == ora.generate(3000)                                 # same tokens, scores, order
+
+
+def test_top_k_leaves_the_vocabulary_exact_or_refuses():
+    """Only the top_k most frequent substrings of a device pass reach the host.  With top_k well above the vocabulary
+    size the generated vocabulary equals the oracle's (which counts everything); with top_k too small the selection
+    would depend on substrings that were cut off, and generate() refuses instead of returning something else."""
+    samples = _samples(512 << 10, seed_offset=5)
+    dev, ora = _both(samples, 16, 1.0, None, ALLOW, ["std::"], ["    "], top_k=60000)
+    want = ora.generate(4000)
+    assert dev.generate(4000) == want and dev.passes == 1
+    assert len(dev.frequencies) < len(ora.frequencies) // 4                        # far fewer strings crossed the link
+    dev2, _ = _both(samples, 16, 1.0, None, ALLOW, top_k=3000)
+    with pytest.raises(tgx.TokenGeeXError, match="top_k too small"):
+        dev2.generate(4000)
+    # several device passes (forced: 64 KiB of text per pass): frequencies add, every pass reports what it cut off
+    import tokengeex_amd.generate as gen_mod
+    old = gen_mod._PASS_BYTES
+    gen_mod._PASS_BYTES = 64 << 10
+    try:
+        dev3, _ = _both(samples, 16, 1.0, None, ALLOW, ["std::"], ["    "], top_k=200000)
+        assert dev3.generate(1500) == ora.generate(1500) and dev3.passes > 4
+    finally:
+        gen_mod._PASS_BYTES = old
 
 
 def test_substring_df_raw_interface():
@@ -63,3 +93,9 @@ def test_substring_df_raw_interface():
     assert n_windows == 10 + 3 + 6
     with pytest.raises(Exception):
         _lib.substring_df(flat, offs[:-1][keep], offs[1:][keep], keep.astype(np.uint32), 17)
+    # top 3: the three substrings that occur in two samples, and the cut-off frequency 1
+    pos, ln, df, _, n_distinct, cut = _lib.substring_df_top(flat, offs[:-1][keep], offs[1:][keep], keep.astype(np.uint32), 4, 3)
+    assert {flat[int(p):int(p + l)].tobytes() for p, l in zip(pos, ln)} == {b"a", b"b", b"ab"} and df.tolist() == [2, 2, 2]
+    assert n_distinct == 13 and cut == 1
+    pos, ln, df, _, n_distinct, cut = _lib.substring_df_top(flat, offs[:-1][keep], offs[1:][keep], keep.astype(np.uint32), 4, 100)
+    assert pos.size == 13 and cut == 0

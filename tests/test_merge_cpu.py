@@ -31,15 +31,34 @@ def test_rust_regex_semantics():
         compile_rust_regex(r"\p{L}+")
 
 
-def test_reference_allow_file_when_present():
-    path = "/root/reference/data/exact.regex"  # not on the GPU box; the fixture above covers the semantics
-    if not os.path.exists(path):
-        pytest.skip("reference checkout not present")
+def test_allow_by_hand_agrees_with_the_translation():
+    """util.AllowByHand (the checker's evaluation of ALLOW, no regex engine) against compile_rust_regex(ALLOW)."""
+    from util import AllowByHand
+    hand, rx = AllowByHand(), compile_rust_regex(ALLOW)
+    cases = ["a", "ab", "Ab", "中文", "!", " ! ", "é", "1", " ", "\t", "aB", "a1", "ab\n", "\n", "", "a b", " é ", "AB",
+             " !", "! ", "  !", "!!", " ", "  ", "，", "A", "Abc", "ABc", "中a", "~", " ~ ", "a ", " a"]
+    for s in cases:
+        assert bool(hand.search(s)) == bool(rx.search(s)), repr(s)
+
+
+def test_reference_allow_file_and_examples():
+    """tests/golden/exact.regex is a byte copy of the reference's data/exact.regex (build_allow_regex over nine named
+    patterns, src/regex.rs:413-425, README.md:49-50); tests/golden/exact_regex_examples.json holds the examples the
+    reference's own test_regexes checks for those patterns (src/regex.rs:178-411, 449-480).  Every accepted example
+    must match the union; plus cases of the Rust semantics that Python's re does not share."""
+    import json
     from tokengeex_amd.merge import load_regex
-    r = load_regex(path)
-    for s in ["'re", " !==", " + ", "...", "  ", "\t\t", "HELLO", "Hello"]:
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    r = load_regex(os.path.join(gold, "exact.regex"))
+    with open(os.path.join(gold, "exact_regex_examples.json"), encoding="utf-8") as f:
+        doc = json.load(f)
+    assert len(doc["patterns"]) == 8
+    for name, ex in doc["patterns"].items():
+        for s in ex["accept"]:
+            assert r.search(s), (name, s)
+    for s in ["'re", " !==", " + ", "...", "  ", "\t\t", "HELLO", "Hello", "()", " [] ", ":="]:
         assert r.search(s), s
-    for s in ["heLLo", " \t", "a+", "ab\n"]:
+    for s in ["heLLo", " \t", "a+", "ab\n", "\t ", "HeLlO", "مرحبا", "123", " WORLD", "'rex"]:
         assert not r.search(s), s
 
 

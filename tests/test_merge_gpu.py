@@ -5,15 +5,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import oracle as orc
-from tokengeex_amd.merge import ModelVocabularyMerger, compile_rust_regex
+from tokengeex_amd.merge import ModelVocabularyMerger
 
-from util import corpus_and_vocab
+from util import AllowByHand, corpus_and_vocab
 from test_merge_cpu import ALLOW
 
 
 def oracle_merge(vocab, flat, offs, allow, num_merges, step, scale_factor, max_token_length):
-    """The reference loop restated over oracle functions only (checker); ties: ascending (a, b)."""
-    rx = compile_rust_regex(allow)
+    """The reference loop restated over oracle functions only (checker); ties: ascending (a, b).  The allow
+    pattern is evaluated by hand (util.AllowByHand), not through the product's pattern translation."""
+    assert allow == ALLOW
+    rx = AllowByHand()
     vocab, start, ignore = list(vocab), len(vocab), set()
     while len(vocab) < start + num_merges:
         m = orc.OracleModel([t[0] for t in vocab], [t[1] for t in vocab])

@@ -96,3 +96,25 @@ def load_vocab_500k():
     scores = z["uscores"][z["inv"]].astype(np.float64)
     assert len(toks) == 500000 and scores.size == 500000
     return toks, scores
+
+
+class AllowByHand:
+    """The allow pattern of the merge / generate tests (test_merge_cpu.ALLOW: any one character | [a-z]+ |
+    [A-Z][a-z]+ | CJK run | one ASCII punctuation mark with optional single spaces around it) evaluated WITHOUT a
+    regex engine, with the meaning Rust's `regex` gives it (`.` = any character but a newline, `$` = end of text,
+    `[[:punct:]]` = ASCII punctuation): the checker's side of the comparison must not go through the product's
+    pattern translation (tokengeex_amd.merge.compile_rust_regex)."""
+    _PUNCT = set("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~")
+
+    def search(self, s: str):
+        if len(s) == 1 and s != "\n":
+            return True
+        if s and all("a" <= c <= "z" for c in s):
+            return True
+        if len(s) >= 2 and "A" <= s[0] <= "Z" and all("a" <= c <= "z" for c in s[1:]):
+            return True
+        if s and all(0x3400 <= ord(c) <= 0x4DBF or 0x4E00 <= ord(c) <= 0x9FFF for c in s):
+            return True
+        core = s[1:] if s.startswith(" ") else s
+        core = core[:-1] if core.endswith(" ") and len(core) > 1 else core
+        return len(core) == 1 and core in self._PUNCT

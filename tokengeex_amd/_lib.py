@@ -71,6 +71,8 @@ SYMBOLS = {
     "tgx_decode_batch": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u64, _i, _pvp, _vp, _pu64, _pu64]),
     "tgx_utf8_lossy": (_u64, [_vp, _u64, _vp]),
     "tgx_substring_df": (_i, [_i, _vp, _u64, _vp, _vp, _vp, _u64, _u32, _d, _u64, _pvp, _pvp, _pvp, _pu64, _pu64, _pu64]),
+    "tgx_substring_df_top": (_i, [_i, _vp, _u64, _vp, _vp, _vp, _u64, _u32, _d, _u64, _u64, _pvp, _pvp, _pvp, _pu64, _pu64, _pu64,
+                                  _pu64, C.POINTER(C.c_uint32)]),
     "tgx_generate_u01": (_d, [_u64, _u64, _u64]),
     "tgx_free": (None, [_vp]),
     "tgx_pool_trim": (None, [_i]),
@@ -289,6 +291,23 @@ def substring_df(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray,
                                C.byref(df), C.byref(n), C.byref(nw), C.byref(nc)))
     k = n.value
     return _take(pos, k, C.c_uint64, np.uint64), _take(ln, k, C.c_uint32, np.uint32), _take(df, k, C.c_uint32, np.uint32), nw.value
+
+
+def substring_df_top(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray, part_sample: np.ndarray,
+                     max_token_length: int, top_k: int, insert_probability: float = 1.0, seed: int = 0, device: int = 0):
+    """The top_k most frequent substrings only (descending frequency; 0 = all)
+    -> (pos, len, df, n_windows, n_distinct, cutoff_df): whatever was cut off occurs in at most cutoff_df samples."""
+    flat = np.ascontiguousarray(flat, np.uint8)
+    pb, pe = np.ascontiguousarray(part_begin, np.uint64), np.ascontiguousarray(part_end, np.uint64)
+    ps = np.ascontiguousarray(part_sample, np.uint32)
+    pos, ln, df, n, nw, nc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    nd, cut = C.c_uint64(), C.c_uint32()
+    check(lib.tgx_substring_df_top(device, ptr(flat) if flat.size else None, flat.size, ptr(pb), ptr(pe), ptr(ps), pb.shape[0],
+                                   max_token_length, float(insert_probability), seed & (2**64 - 1), int(top_k), C.byref(pos),
+                                   C.byref(ln), C.byref(df), C.byref(n), C.byref(nw), C.byref(nc), C.byref(nd), C.byref(cut)))
+    k = n.value
+    return (_take(pos, k, C.c_uint64, np.uint64), _take(ln, k, C.c_uint32, np.uint32), _take(df, k, C.c_uint32, np.uint32),
+            nw.value, nd.value, cut.value)
 
 
 def generate_u01(seed: int, sample: int, window_hash: int) -> float:

@@ -183,12 +183,14 @@ double tgx_generate_u01(uint64_t seed, uint64_t sample, uint64_t window_hash) { 
 // of one occurrence and the number of samples it occurs in — malloc'd (tgx_free), in ascending order of the
 // substrings' FNV-1a hashes.  *n_collisions > 0 (two different substrings with one 64-bit hash) makes the
 // call fail with TGX_ERR_UNSUPPORTED: callers fall back to the host path.  text must be < 4 GiB.
-tgx_status tgx_substring_df(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
-                            const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
-                            uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t** out_pos,
-                            uint32_t** out_len, uint32_t** out_df, uint64_t* n_out, uint64_t* n_windows,
-                            uint64_t* n_collisions) {
+static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
+                                    const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
+                                    uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t top_k,
+                                    uint64_t** out_pos, uint32_t** out_len, uint32_t** out_df, uint64_t* n_out,
+                                    uint64_t* n_windows, uint64_t* n_collisions, uint64_t* n_distinct, uint32_t* cutoff_df) {
     using namespace tgx;
+    if (n_distinct) *n_distinct = 0;
+    if (cutoff_df) *cutoff_df = 0;
     if (!out_pos || !out_len || !out_df || !n_out) return tgx_set_error(TGX_ERR_INVALID, "tgx_substring_df: NULL argument");
     *out_pos = nullptr;
     *out_len = nullptr;
@@ -344,10 +346,34 @@ tgx_status tgx_substring_df(int device, const uint8_t* text, uint64_t n_bytes, c
     const unsigned long long coll = ctr[0];
     if (n_collisions) *n_collisions = coll;
     if (coll) return fail(TGX_ERR_UNSUPPORTED, "tgx_substring_df: two different substrings share a 64-bit hash: use the host path for this batch");
+    if (n_distinct) *n_distinct = n_runs;
+    // top_k: only the top_k most frequent substrings leave the device (VocabularyGenerator::generate keeps the most
+    // frequent ones, src/generate.rs:150-152, 199-213): a stable descending radix sort of (df, representative) —
+    // equal frequencies stay in ascending hash order —, and the frequency of the first substring that is cut off
+    uint64_t n_ret = n_runs;
+    if (top_k && top_k < n_runs) {
+        uint32_t* d_df2 = (uint32_t*)dalloc((size_t)n_runs * 4);
+        uint64_t* d_rep2 = (uint64_t*)dalloc((size_t)n_runs * 8);
+        if (!d_df2 || !d_rep2) return fail(TGX_ERR_DEVICE, "out of device memory (generate: top-k)");
+        size_t tb = 0;
+        G_TRY(rocprim::radix_sort_pairs_desc(nullptr, tb, d_df, d_df2, d_rep, d_rep2, (size_t)n_runs));
+        void* tmp = dalloc(tb);
+        if (!tmp) return fail(TGX_ERR_DEVICE, "out of device memory (generate: top-k sort)");
+        G_TRY(rocprim::radix_sort_pairs_desc(tmp, tb, d_df, d_df2, d_rep, d_rep2, (size_t)n_runs));
+        uint32_t cut = 0;
+        G_TRY(hipMemcpy(&cut, d_df2 + top_k, 4, hipMemcpyDeviceToHost));
+        if (cutoff_df) *cutoff_df = cut;
+        d_df = d_df2;
+        d_rep = d_rep2;
+        n_ret = top_k;
+    }
+    const uint32_t n_runs_all = n_runs;
+    (void)n_runs_all;
+    n_runs = (uint32_t)n_ret;
     std::vector<uint64_t> rep(n_runs);
-    uint64_t* pos = (uint64_t*)malloc(sizeof(uint64_t) * n_runs);
-    uint32_t* len = (uint32_t*)malloc(sizeof(uint32_t) * n_runs);
-    uint32_t* df = (uint32_t*)malloc(sizeof(uint32_t) * n_runs);
+    uint64_t* pos = (uint64_t*)malloc(sizeof(uint64_t) * std::max<uint32_t>(n_runs, 1));
+    uint32_t* len = (uint32_t*)malloc(sizeof(uint32_t) * std::max<uint32_t>(n_runs, 1));
+    uint32_t* df = (uint32_t*)malloc(sizeof(uint32_t) * std::max<uint32_t>(n_runs, 1));
     if (!pos || !len || !df) {
         free(pos);
         free(len);
@@ -372,6 +398,28 @@ tgx_status tgx_substring_df(int device, const uint8_t* text, uint64_t n_bytes, c
     *out_df = df;
     *n_out = n_runs;
     return TGX_OK;
+}
+
+tgx_status tgx_substring_df(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
+                            const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
+                            uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t** out_pos,
+                            uint32_t** out_len, uint32_t** out_df, uint64_t* n_out, uint64_t* n_windows,
+                            uint64_t* n_collisions) {
+    return substring_df_impl(device, text, n_bytes, part_begin, part_end, part_sample, n_parts, max_token_length,
+                             insert_probability, seed, 0, out_pos, out_len, out_df, n_out, n_windows, n_collisions, nullptr, nullptr);
+}
+
+// The same with only the top_k most frequent substrings returned (descending frequency; 0 = all): *n_distinct = the
+// number of distinct substrings counted, *cutoff_df = the frequency of the most frequent substring that was NOT
+// returned (0 when nothing was cut) — every substring that is not in the output occurs in at most that many
+// samples, which is what lets a caller that accumulates several calls decide whether its selection is exact.
+tgx_status tgx_substring_df_top(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
+                                const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
+                                uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t top_k,
+                                uint64_t** out_pos, uint32_t** out_len, uint32_t** out_df, uint64_t* n_out,
+                                uint64_t* n_windows, uint64_t* n_collisions, uint64_t* n_distinct, uint32_t* cutoff_df) {
+    return substring_df_impl(device, text, n_bytes, part_begin, part_end, part_sample, n_parts, max_token_length,
+                             insert_probability, seed, top_k, out_pos, out_len, out_df, n_out, n_windows, n_collisions, n_distinct, cutoff_df);
 }
 
 }  // extern "C"

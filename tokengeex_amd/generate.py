@@ -2,20 +2,28 @@
 initial vocabulary `prune` starts from.
 
 `feed` counts, for every char-aligned substring of at most max_token_length bytes, the samples it occurs in
-(src/generate.rs:54-139).  With a device (the default) that is `tgx_substring_df` (csrc/generate.hip): one
-lane per byte position hashes its windows, a radix sort groups equal substrings, a run pass counts distinct
-samples; the split regex reaches the device as byte ranges, the allow regex — a pure function of the
-candidate — is applied on the host to the DISTINCT substrings that come back, and the added / suggested
-tokens are searched on the host as in the reference.  With `device=None` the same counts come from
-`_feed_host`, the per-sample Python restatement of the reference's loops: the checker of the device path
-(tests) and the path for max_token_length > 16.
+(src/generate.rs:54-139).  Here that is `tgx_substring_df[_top]` (csrc/generate.hip): one lane per byte position
+hashes its windows, a radix sort groups equal substrings, a run pass counts distinct samples; the split regex
+reaches the device as byte ranges, the allow regex — a pure function of the candidate — is applied on the host to
+the substrings that come back, and the added / suggested tokens are searched on the host as in the reference.
+There is no host fallback: without a GPU (or for max_token_length > 16) the calls fail.  The checker of this path
+is the CPU oracle's restatement of the generator (test infrastructure, never imported here).
+
+Round 3: `top_k`.  `generate(size)` keeps the most frequent substrings (src/generate.rs:150-152, 199-213), so only
+the top_k most frequent ones of a device pass leave the device (the pass over 64 MiB of text finds 254 M distinct
+substrings; turning each into a Python string, an allow-regex call and a dictionary entry was what bounded `feed`:
+0.4 MB/s).  Samples are buffered by `feed` and counted in as few device passes as fit (`generate` and
+`frequencies` trigger them), because frequencies add over passes but a truncated pass only bounds what it cut off:
+every pass reports the frequency of the first substring it cut, `generate` adds those bounds up and REFUSES
+(TokenGeeXError) to return a vocabulary that a cut-off substring could have changed — a larger top_k, or fewer
+passes, make it exact again.  With top_k = None everything is returned and nothing can be uncertain.
 
 Differences from the reference, both forced: the reference draws `rng.gen_range(0.0..1.0)` from an unseeded
 thread RNG for `insert_probability` (src/generate.rs:88,112,126), here a counter hash of (seed, sample,
-FNV-1a-64 of the candidate's bytes) decides — the same function on the device and on the host — so runs are
-reproducible; tokens of equal frequency / score are ordered by their bytes (`sort_unstable_by` leaves their
-order unspecified), so the device path and the host path give the same vocabulary.  The split regex
-(fancy_regex) is taken as a compiled Python pattern.
+FNV-1a-64 of the candidate's bytes) decides — tgx_generate_u01, the same function on the device and in the
+CPU oracle — so runs are reproducible; tokens of equal frequency / score are ordered by their bytes
+(`sort_unstable_by` leaves their order unspecified).  The split regex (fancy_regex) is taken as a compiled Python
+pattern.
 """
 from __future__ import annotations
 
@@ -23,9 +31,11 @@ import math
 
 import numpy as np
 
+from . import _lib
 from .merge import compile_rust_regex
 
 _M64 = (1 << 64) - 1
+_PASS_BYTES = 1 << 30  # text per device pass (tgx_substring_df takes < 4 GiB and < 2^32 kept windows)
 
 
 def _fnv1a64(data: bytes) -> int:
@@ -37,57 +47,62 @@ def _fnv1a64(data: bytes) -> int:
 
 def _u01(seed: int, sample: int, token: str) -> float:
     """tgx_generate_u01(seed, sample, FNV-1a-64(token bytes)) — include/tgx.h, csrc/generate.hip."""
-    h = _fnv1a64(token.encode("utf-8", "surrogatepass"))
-    x = (seed ^ (sample * 0x9E3779B97F4A7C15) ^ (h * 0xC2B2AE3D27D4EB4F)) & _M64
-    x ^= x >> 30
-    x = (x * 0xBF58476D1CE4E5B9) & _M64
-    x ^= x >> 27
-    x = (x * 0x94D049BB133111EB) & _M64
-    x ^= x >> 31
-    return (x >> 11) * (1.0 / 9007199254740992.0)
+    return _lib.generate_u01(seed, sample, _fnv1a64(token.encode("utf-8", "surrogatepass")))
 
 
 class VocabularyGenerator:
     """VocabularyGenerator::new(max_token_length, insert_probability, split, allow, added, suggested)."""
 
     def __init__(self, max_token_length: int, insert_probability: float, split=None, allow=None,
-                 added_tokens=(), suggested_tokens=(), seed: int = 0, device: int | None = 0):
-        self.device = device  # None: the host restatement (checker); an int: substring counting on that GPU
+                 added_tokens=(), suggested_tokens=(), seed: int = 0, device: int = 0, top_k: int | None = None):
+        if device is None:
+            raise _lib.TokenGeeXError("VocabularyGenerator counts on a GPU: there is no host path")
+        if int(max_token_length) > 16:
+            raise _lib.TokenGeeXError("VocabularyGenerator: max_token_length must be <= 16 (tgx_substring_df)")
+        if _lib.device_count() <= int(device):
+            raise _lib.TokenGeeXError("VocabularyGenerator: no usable HIP device (gfx950 required); there is no CPU fallback")
+        self.device = int(device)
         self.max_token_length = int(max_token_length)
         self.insert_probability = float(insert_probability)
         self.split = split
         self.allow = compile_rust_regex(allow) if isinstance(allow, str) else allow
         self.added_tokens, self.suggested_tokens = list(added_tokens), list(suggested_tokens)
         self.seed = seed
-        self._fed = 0
-        self.frequencies: dict[str, int] = {}
+        self.top_k = int(top_k) if top_k else 0
+        self._fed = 0                       # samples seen (the keep rule hashes the global sample index)
+        self._pending: list[str] = []       # fed, not yet counted
+        self._pending_first = 0
+        self._freq: dict[str, int] = {}
+        self._bound_seen: dict[str, int] = {}  # per substring: the cut-off bounds of the passes that DID return it
+        self._bound_total = 0               # sum over passes of the frequency of the first substring cut off
+        self.passes = 0
         for t in self.added_tokens + self.suggested_tokens:  # src/generate.rs:33-41
-            self.frequencies[t] = self.frequencies.get(t, 0) + 1
+            self._freq[t] = self._freq.get(t, 0) + 1
 
     def _keep(self, sample_index: int, token: str) -> bool:
         return self.insert_probability >= 1.0 or _u01(self.seed, sample_index, token) < self.insert_probability
 
-    def _candidates(self, part: str, sample_index: int, out: set):
-        """src/generate.rs:72-96 / 99-120: every char-aligned substring of at most max_token_length BYTES."""
-        n = len(part)
-        blen = [len(c.encode("utf-8", "surrogatepass")) for c in part]
-        for i in range(n):
-            total = 0
-            for j in range(i, n):
-                total += blen[j]
-                if total > self.max_token_length:
-                    break
-                cand = part[i:j + 1]
-                if (self.allow is None or self.allow.search(cand)) and self._keep(sample_index, cand):
-                    out.add(cand)
-
     def feed(self, samples: list[str]) -> None:
-        """feed(&mut self, samples) — src/generate.rs:54-139: DOCUMENT frequencies (one count per sample)."""
-        if self.device is None or self.max_token_length > 16:
-            return self._feed_host(samples)
-        from . import _lib
-        first = self._fed
+        """feed(&mut self, samples) — src/generate.rs:54-139: DOCUMENT frequencies (one count per sample).
+        The samples are counted by the next device pass (as many samples as fit one pass at a time)."""
+        if not self._pending:
+            self._pending_first = self._fed
+        self._pending.extend(samples)
         self._fed += len(samples)
+        if sum(len(s) for s in self._pending) >= _PASS_BYTES:
+            self._flush()
+
+    def _flush(self) -> None:
+        while self._pending:
+            n, size = 0, 0
+            while n < len(self._pending) and (n == 0 or size + len(self._pending[n]) <= _PASS_BYTES):
+                size += len(self._pending[n])
+                n += 1
+            self._count(self._pending[:n], self._pending_first)
+            self._pending = self._pending[n:]
+            self._pending_first += n
+
+    def _count(self, samples: list[str], first: int) -> None:
         enc = [s.encode("utf-8", "surrogatepass") for s in samples]
         flat, offs = _lib.pack(enc)
         if self.split is None:
@@ -112,18 +127,22 @@ class VocabularyGenerator:
             pb, pe, ps = np.array(pb_l, np.uint64), np.array(pe_l, np.uint64), np.array(ps_l, np.uint32)
         extra = self.added_tokens + self.suggested_tokens
         extra_set = set(extra)
+        self.passes += 1
         if pb.size:
             # the keep rule sees the global sample index (the device packs it into 27 bits)
-            pos, ln, df, _ = _lib.substring_df(flat, pb, pe, (ps.astype(np.uint64) + first).astype(np.uint32),
-                                               self.max_token_length, self.insert_probability, self.seed, self.device)
+            pos, ln, df, _, _, cut = _lib.substring_df_top(flat, pb, pe, (ps.astype(np.uint64) + first).astype(np.uint32),
+                                                           self.max_token_length, self.top_k, self.insert_probability, self.seed, self.device)
+            self._bound_total += cut
             raw = flat.tobytes()
             for p_, l_, d_ in zip(pos.tolist(), ln.tolist(), df.tolist()):
                 cand = raw[p_:p_ + l_].decode("utf-8", "surrogatepass")
                 if cand in extra_set:
                     continue  # counted below: a sample's set holds the token once, whichever rule put it there
                 if self.allow is None or self.allow.search(cand):
-                    self.frequencies[cand] = self.frequencies.get(cand, 0) + d_
-        # added and suggested tokens: any occurrence in the sample counts (src/generate.rs:122-131).  The keep
+                    self._freq[cand] = self._freq.get(cand, 0) + d_
+                    if cut:
+                        self._bound_seen[cand] = self._bound_seen.get(cand, 0) + cut
+        # added and suggested tokens: any occurrence in the sample counts (src/generate.rs:117-127).  The keep
         # rule is a function of (seed, sample, token), so a window of the same text made the same decision and
         # the union of both rules is this one.
         for t in dict.fromkeys(extra):
@@ -131,43 +150,35 @@ class VocabularyGenerator:
                 continue
             n = sum(1 for i, sample in enumerate(samples) if t in sample and self._keep(first + i, t))
             if n:
-                self.frequencies[t] = self.frequencies.get(t, 0) + n
+                self._freq[t] = self._freq.get(t, 0) + n
 
-    def _feed_host(self, samples: list[str]) -> None:
-        """The reference's loops per sample, in Python: the checker of the device path."""
-        for sample in samples:
-            idx = self._fed
-            self._fed += 1
-            toks: set = set()
-            if self.split is not None:
-                for m in self.split.finditer(sample):
-                    self._candidates(m.group(0), idx, toks)
-            else:
-                self._candidates(sample, idx, toks)
-            for t in self.added_tokens + self.suggested_tokens:  # src/generate.rs:122-131
-                if t and t in sample and self._keep(idx, t):
-                    toks.add(t)
-            for t in toks:
-                self.frequencies[t] = self.frequencies.get(t, 0) + 1
+    @property
+    def frequencies(self) -> dict[str, int]:
+        """The counts so far (of the substrings that left the device: all of them without top_k)."""
+        self._flush()
+        return self._freq
 
     def current_size(self) -> int:
         return len(self.frequencies)
 
     def generate(self, size: int) -> list[tuple[bytes, float, bool]]:
         """generate(&mut self, size) — src/generate.rs:148-243 -> [(value, log-probability, keep)]."""
+        freqs = self.frequencies
         # (ties: ascending token bytes — the reference's sort_unstable_by leaves their order unspecified; a fixed
         # rule makes the result independent of the order in which the counts arrived)
-        frequent = sorted(self.frequencies.items(), key=lambda kv: (-kv[1], kv[0].encode("utf-8", "surrogatepass")))
+        frequent = sorted(freqs.items(), key=lambda kv: (-kv[1], kv[0].encode("utf-8", "surrogatepass")))
         highest = frequent[0][1] if frequent else 1
         seen = {bytes([b]) for b in range(255)}
         vocab = [(bytes([b]), float(highest), True) for b in range(255)]  # bytes 0..254, src/generate.rs:164-169
+        extra = set(self.added_tokens) | set(self.suggested_tokens)  # counted exactly on the host, whatever top_k
         for tok, keep in [(t, True) for t in self.added_tokens] + [(t, False) for t in self.suggested_tokens]:
             if len(vocab) >= size:
                 break
             b = tok.encode("utf-8")
             if b not in seen and len(b) > 1:
                 seen.add(b)
-                vocab.append((b, float(self.frequencies[tok] * len(b)), keep))
+                vocab.append((b, float(freqs[tok] * len(b)), keep))
+        last_freq, chosen = None, []
         for tok, freq in frequent:
             if len(vocab) >= size:
                 break
@@ -175,6 +186,29 @@ class VocabularyGenerator:
             if b not in seen and len(b) > 1:
                 seen.add(b)
                 vocab.append((b, float(freq * len(b)), False))
+                if tok not in extra:
+                    chosen.append(tok)
+                    last_freq = freq
+        if self._bound_total:
+            # Some pass cut substrings off.  The selection is exact iff every chosen substring came back from every
+            # pass that cut anything (its count is complete) and no substring outside the selection can reach the
+            # frequency of the last one chosen: a cut-off substring occurs in at most `cutoff` samples of its pass.
+            floor = last_freq if (last_freq is not None and len(vocab) >= size) else 0
+            if highest < self._bound_total:
+                raise _lib.TokenGeeXError("VocabularyGenerator: top_k too small: a substring that was cut off could be the most frequent one")
+            for tok in chosen:
+                if self._bound_seen.get(tok, 0) != self._bound_total:
+                    raise _lib.TokenGeeXError(f"VocabularyGenerator: top_k too small for an exact vocabulary: {tok!r} was cut off in some pass "
+                                              f"({self.passes} passes; feed fewer, larger batches or raise top_k)")
+            chosen_set = set(chosen)
+            if floor <= self._bound_total:  # a substring no pass returned could tie with or beat the last one chosen
+                raise _lib.TokenGeeXError("VocabularyGenerator: top_k too small for an exact vocabulary: the selection reaches "
+                                          f"frequency {floor}, substrings of up to {self._bound_total} samples were cut off")
+            for tok, freq in freqs.items():
+                if tok in chosen_set or tok in extra or len(tok.encode("utf-8", "surrogatepass")) <= 1:
+                    continue
+                if freq + self._bound_total - self._bound_seen.get(tok, 0) >= floor and freq < floor:
+                    raise _lib.TokenGeeXError(f"VocabularyGenerator: top_k too small for an exact vocabulary: {tok!r} may belong to it")
         vocab.sort(key=lambda t: (-t[1], t[0]))
         logsum = math.log(sum(t[1] for t in vocab))  # logprobs, src/generate.rs:245-251
         out = []

@@ -86,6 +86,8 @@ class ModelVocabularyMerger:
         # rank (dist.allreduce_pairs), so all ranks pick the same merges
         self.dist, self.reduce_device = dist, reduce_device
         self.head_pairs = 1 << 18  # pairs fetched per round in single-process mode
+        self.exchange_pairs = 1 << 12  # pairs every rank contributes to a round's exchange (multi-rank mode)
+        self.exchanged_bytes = 0     # bytes this rank has gathered / reduced for the pair exchange so far
         self.rounds: list[dict] = []
 
     def select(self, vocab, keys: np.ndarray, counts: np.ndarray, budget: int, ignore: set):
@@ -127,7 +129,21 @@ class ModelVocabularyMerger:
                     if keys.size < total and len(self.select(vocab, keys, counts, budget, set(ignore))) < budget:
                         keys, counts = model.count_pairs(corpus)
                 else:
-                    keys, counts = tdist.allreduce_pairs(*model.count_pairs(corpus), self.dist, self.reduce_device)
+                    # several ranks: only the head of the global table is ever looked at, so the ranks exchange their
+                    # local heads and the exact counts of the union (dist.top_pairs_exchange: ~1 MB per round instead
+                    # of every rank's whole table); candidates above `bound` are provably the global head.  Widened
+                    # (x 4) when the selection would have to go below the bound — every rank takes the same decision.
+                    lk, lc = model.count_pairs(corpus)
+                    k = self.exchange_pairs
+                    while True:
+                        keys, counts, bound, nbytes = tdist.top_pairs_exchange(lk, lc, k, self.dist, self.reduce_device)
+                        self.exchanged_bytes += nbytes
+                        sure = counts.astype(np.int64) > bound
+                        keys, counts = keys[sure], counts[sure]
+                        # (bound 0: every rank contributed its whole table)
+                        if bound == 0 or len(self.select(vocab, keys, counts, budget, set(ignore))) >= budget:
+                            break
+                        k *= 4
                 t1 = time.perf_counter()
                 model.free()
                 new = self.select(vocab, keys, counts, budget, ignore)
