@@ -77,8 +77,15 @@ def test_top_k_leaves_the_vocabulary_exact_or_refuses():
     old = gen_mod._PASS_BYTES
     gen_mod._PASS_BYTES = 64 << 10
     try:
-        dev3, _ = _both(samples, 16, 1.0, None, ALLOW, ["std::"], ["    "], top_k=200000)
+        dev3, _ = _both(samples, 16, 1.0, None, ALLOW, ["std::"], ["    "], top_k=1000000)   # nothing is cut in a 64 KiB pass
         assert dev3.generate(1500) == ora.generate(1500) and dev3.passes > 4
+        # ... and when every small pass cuts something, the bounds add up: the result is the oracle's or a refusal,
+        # never a different vocabulary
+        dev4, _ = _both(samples, 16, 1.0, None, ALLOW, ["std::"], ["    "], top_k=150000)
+        try:
+            assert dev4.generate(1500) == ora.generate(1500)
+        except tgx.TokenGeeXError as e:
+            assert "top_k too small" in str(e)
     finally:
         gen_mod._PASS_BYTES = old
 
