@@ -1354,9 +1354,13 @@ tgx_status tgx_encode_batch_host(tgx_model* m, const uint8_t* text, const uint64
     uint64_t err_sample = 0, err_pos = 0, err_len = 0;
     bool abort_all = false;
     size_t downloaded = 0;
+    uint64_t err_base = ~0ull;  // first sample of the chunk the recorded error belongs to
     auto set_error = [&](tgx_status st, uint64_t sample_base) {  // under mu; g_err_* are this thread's
-        if (first_err == TGX_OK) {
+        // the error of the LOWEST chunk is the batch's (an upload failure of a later chunk must not hide the NoPath of
+        // an earlier one that is still being encoded: the encoder records its own when it gets there)
+        if (first_err == TGX_OK || sample_base < err_base) {
             first_err = st;
+            err_base = sample_base;
             err_msg = g_err_msg;
             err_sample = g_err_sample + sample_base;
             err_pos = g_err_pos;
@@ -1402,7 +1406,8 @@ tgx_status tgx_encode_batch_host(tgx_model* m, const uint8_t* text, const uint64
                 cv.wait(lk, [&]() { return abort_all || cs[k].stage >= 1; });
                 if (cs[k].stage < 1) return;  // aborted before this chunk was uploaded
                 c = cs[k].corpus;
-                if (abort_all) continue;      // (the main thread frees what is left)
+                if (abort_all && cut[k] >= err_base) continue;  // (the main thread frees what is left; a chunk BELOW a
+                                                                // failed upload is still encoded: its own error would come first)
             }
             tgx_result* r = nullptr;
             const auto t0 = std::chrono::steady_clock::now();
@@ -1445,12 +1450,16 @@ tgx_status tgx_encode_batch_host(tgx_model* m, const uint8_t* text, const uint64
         }
         base += r->n_tokens;
         stamp("download", k, t0);
+        // the chunk's ids are in the caller's memory: its device buffers go back to the pool now (a batch larger
+        // than the free HBM streams through; kept until the end they grew by a byte per input byte)
+        if (st2 == TGX_OK) tgx_result_free(r);
         std::lock_guard<std::mutex> lk(mu);
         if (st2 != TGX_OK) {
             g_err_sample = 0;
             set_error(st2, 0);
             break;
         }
+        cs[k].result = nullptr;
         cs[k].stage = 3;
         downloaded = k + 1;
         cv.notify_all();
