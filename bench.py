@@ -104,7 +104,16 @@ def main() -> None:
         toks, scores = synth.build_vocab(vflat[: slice_mib << 20], args.vocab, args.max_token_length)
     scores = np.asarray(scores, np.float64)
     if args.distinct_scores:
+        # as after an M-step (reference src/prune.rs:124-151: score = digamma(max(freq, 0.5)) - digamma(sum)): every
+        # token that occurs gets a score of its own; the single-byte tokens that never occur in the corpus (control
+        # characters, bytes no UTF-8 text contains) all sit on the floor value, as they do there
         scores = scores + np.random.default_rng(5).uniform(-0.4, 0.4, len(toks))
+        seen = np.zeros(256, bool)
+        seen[np.unique(synth.make_corpus(8 << 20, args.kind, seed_offset=1000)[0])] = True
+        floor = float(scores.min()) - 1.0
+        for i, t in enumerate(toks):
+            if len(t) == 1 and not seen[t[0]]:
+                scores[i] = floor
     n_values = int(np.unique(scores).size)
     flat, offs = synth.make_corpus(args.size_mb << 20, args.kind, max_len=args.max_sample_len, seed_offset=1000 + rank)
     n_bytes, n_samples = int(flat.size), int(offs.size - 1)

@@ -342,8 +342,11 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
                 fin[g] = kNoStep;
                 uint32_t fhi = 0xFFF00000u;
                 if (COLD) {
-                    double sv[8];
+                    // both halves' cold values are requested before the first step: the loads sit behind branches, so
+                    // the compiler waits for all of them at the first use — one exposed L2 round trip per group, not two
+                    double sv[8], sw[8];
                     e5_scores_cold<8>(lds0, cold_values, cw, 0, hot_bytes, sv);
+                    e5_scores_cold<8>(lds0, cold_values, cw, 8, hot_bytes, sw);
                     if (g + 1 < PPL) load_iw(g + 1, nw);
                     relax5_step<0>(sv[0], acc, bpv, fin[g], fhi);
                     relax5_step<1>(sv[1], acc, bpv, fin[g], fhi);
@@ -353,15 +356,14 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
                     relax5_step<5>(sv[5], acc, bpv, fin[g], fhi);
                     relax5_step<6>(sv[6], acc, bpv, fin[g], fhi);
                     relax5_step<7>(sv[7], acc, bpv, fin[g], fhi);
-                    e5_scores_cold<8>(lds0, cold_values, cw, 8, hot_bytes, sv);
-                    relax5_step<8>(sv[0], acc, bpv, fin[g], fhi);
-                    relax5_step<9>(sv[1], acc, bpv, fin[g], fhi);
-                    relax5_step<10>(sv[2], acc, bpv, fin[g], fhi);
-                    relax5_step<11>(sv[3], acc, bpv, fin[g], fhi);
-                    relax5_step<12>(sv[4], acc, bpv, fin[g], fhi);
-                    relax5_step<13>(sv[5], acc, bpv, fin[g], fhi);
-                    relax5_step<14>(sv[6], acc, bpv, fin[g], fhi);
-                    relax5_step<15>(sv[7], acc, bpv, fin[g], fhi);
+                    relax5_step<8>(sw[0], acc, bpv, fin[g], fhi);
+                    relax5_step<9>(sw[1], acc, bpv, fin[g], fhi);
+                    relax5_step<10>(sw[2], acc, bpv, fin[g], fhi);
+                    relax5_step<11>(sw[3], acc, bpv, fin[g], fhi);
+                    relax5_step<12>(sw[4], acc, bpv, fin[g], fhi);
+                    relax5_step<13>(sw[5], acc, bpv, fin[g], fhi);
+                    relax5_step<14>(sw[6], acc, bpv, fin[g], fhi);
+                    relax5_step<15>(sw[7], acc, bpv, fin[g], fhi);
                 } else {
                     e5_scores_issue<4>(lds0, cw, 4, sb);
                     if (g + 1 < PPL) load_iw(g + 1, nw);
