@@ -258,14 +258,16 @@ def test_every_positions_per_lane_variant(monkeypatch, ppl, path):
     assert_same_encoding(nat, ora, f2, o2)
 
 
-@pytest.mark.parametrize("path", ["default", "rows2"])
+@pytest.mark.parametrize("path", ["default", "rows4l", "rows2"])
 @pytest.mark.parametrize("max_len", [17, 20, 24, 32])
 def test_long_token_vocabularies(monkeypatch, max_len, path):
-    """Vocabularies whose longest token has 17..32 bytes (after `merge`): encode4l_kernel (16-lane rows with an
-    overflow list for the long matches) by default, encode2_kernel (two samples per wave) with TGX_PATH=rows2;
-    both bit-exact against the oracle incl. dropout, ties, block-boundary lengths and unreachable ends."""
-    if path == "rows2":
-        monkeypatch.setenv("TGX_PATH", "rows2")
+    """Vocabularies whose longest token has 17..32 bytes (after `merge`): the LONG build of encode5_kernel by default
+    (round 3: rank indices, a list of long matches per wave, the slow steps only where a long match is pending),
+    encode4l_kernel (round 1: 16-byte records, scores through the match buffer) with TGX_PATH=rows4l, encode2_kernel
+    (two samples per wave) with TGX_PATH=rows2; all bit-exact against the oracle incl. dropout, ties, block-boundary
+    lengths and unreachable ends; the default also with every token its own score and a small LDS copy."""
+    if path != "default":
+        monkeypatch.setenv("TGX_PATH", path)
     rng = np.random.default_rng(4000 + max_len)
     flat, offs = synth.make_corpus(384 << 10, "mixed", seed_offset=50 + max_len, max_len=20000)
     toks, scores = synth.random_vocab(rng, bytes(flat[: 96 << 10]), n_multi=4000, max_len=max_len, tie_fraction=0.5)
@@ -273,12 +275,19 @@ def test_long_token_vocabularies(monkeypatch, max_len, path):
     assert 16 < nat.max_token_len <= max_len
     assert_same_encoding(nat, ora, flat, offs)
     kt = nat.last_kernel_times()
-    assert ("encode2_kernel" if path == "rows2" else "encode4l_kernel") in kt and "trace32_kernel" in kt
+    assert {"default": "encode5_kernel", "rows4l": "encode4l_kernel", "rows2": "encode2_kernel"}[path] in kt and "trace32_kernel" in kt
     assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=9)
     longest = max(toks, key=len)
     texts = [b"", b"a", longest, longest * 3, b"ab" * 16, b"ab" * 16 + b"a", b"ab" * 32, b"q" * 31, b"q" * 33, b"hello world " * 40]
     f2, o2 = tgx.pack(texts)
     assert_same_encoding(nat, ora, f2, o2)
+    if path == "default":
+        sc3 = np.asarray(scores, np.float64) - rng.random(len(toks)) * 1e-3
+        nat3, ora3 = tgx.NativeModel(toks, sc3), orc.OracleModel(toks, sc3)
+        monkeypatch.setenv("TGX_E5_HOT", "500")   # most values outside the LDS copy
+        assert_same_encoding(nat3, ora3, flat, offs)
+        assert "encode5_kernel" in nat3.last_kernel_times() and nat3.last_encode_hot_values() == 500
+        assert_same_encoding(nat3, ora3, f2, o2)
 
 
 def test_long_token_overflow_redoes_only_the_samples_concerned():
@@ -294,9 +303,9 @@ def test_long_token_overflow_redoes_only_the_samples_concerned():
     flat, offs = tgx.pack(texts)
     assert_same_encoding(nat, ora, flat, offs)
     kt = nat.last_kernel_times()
-    assert "encode4l_kernel" in kt and "encode2_kernel" in kt
+    assert "encode5_kernel" in kt and "encode2_kernel" in kt
     # the three samples with long runs of "a" and at most the three others of each of their waves
-    assert 3 <= nat.last_encode_redo_samples() <= 12
+    assert 3 <= nat.last_encode_redo_samples() <= 40   # (a wave works on four samples at a time, 256 positions per iteration)
     # dropout: the redone samples draw the same per-(sample, position, length) numbers in either kernel
     assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=5)
     assert nat.last_encode_redo_samples() >= 1

@@ -84,7 +84,7 @@ struct WalkCtx {
 // not exist — and the stagger would be lost; lanes reading record 0 cost the texture path next to nothing,
 // profiles/r03/d_gather3_dead_lanes.txt.  For the same reason the hottest slots are NOT read from an LDS copy:
 // tried, 2 % at best, a step still waits for its slowest lane, which goes to L2.)
-template <bool DROPOUT, int PPL, int D>
+template <bool DROPOUT, bool LONG, int PPL, int D>
 struct Walk5 {
     // rec[g], c[g]: record and text byte of depth D of walk g (the load may still be in flight)
     static __device__ __forceinline__ void run(const WalkCtx<PPL>& W, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
@@ -109,17 +109,17 @@ struct Walk5 {
                 alive[g] = alive[g] && ((uint32_t)e < maxd[g]);
                 const uint32_t off = (rec[g].x ^ (c[g] << 3)) & 0xFFFFFFu;
                 rec[g] = buf_ld8(W.trie, alive[g] ? off : 0u);
-            } else {
+            } else if (!LONG) {
                 alive[g] = false;
-            }
+            }  // LONG: alive[g] says whether the walk goes on past 16 bytes (rec[g] is its record of depth 15): e5_long_tail
             any = any || alive[g];
         }
         if (__builtin_amdgcn_ballot_w64(any) == 0) return;
-        Walk5<DROPOUT, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
+        Walk5<DROPOUT, LONG, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
     }
 };
-template <bool DROPOUT, int PPL>
-struct Walk5<DROPOUT, PPL, 16> {
+template <bool DROPOUT, bool LONG, int PPL>
+struct Walk5<DROPOUT, LONG, PPL, 16> {
     static __device__ __forceinline__ void run(const WalkCtx<PPL>&, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL],
                                                const uint32_t (&)[PPL], const uint32_t (&)[PPL], bool (&)[PPL], uint2 (&)[PPL],
                                                uint32_t (&)[PPL]) {}
@@ -168,6 +168,90 @@ __device__ __forceinline__ void e5_scores_cold(uint32_t tab, __amdgpu_buffer_rsr
         if (a[u] >= hot_bytes) sv[u] = buf_ld_f64(cold, a[u] - hot_bytes);
 }
 
+// one score by its rank (the rare paths of the LONG builds): LDS copy, or the rest of the table under a branch
+template <bool COLD>
+__device__ __forceinline__ double e5_score_one(uint32_t tab, __amdgpu_buffer_rsrc_t cold, uint32_t rank, uint32_t hot_bytes) {
+    const uint32_t a = rank << 3;
+    double v = lds_ld<double>(tab + ((!COLD || a < hot_bytes) ? a : 0u));
+    if (COLD) {
+        asm volatile("" : "+v"(v));
+        if (a >= hot_bytes) v = buf_ld_f64(cold, a - hot_bytes);
+    }
+    return v;
+}
+
+// ---- LONG builds: vocabularies whose longest token has 17..32 bytes (after `merge`: src/cli.rs:723 defaults to 24) ----
+// Such tokens are RARE matches (23 of the 32 600 tokens of a merged vocabulary), so the kernel keeps its 16-column
+// structure and adds what encode4l_kernel (encode4l.hip, round 1) adds to encode4_kernel, but only on the paths that
+// meet a long match: the walk goes on past depth 16 only where the trie continues (e5_long_tail, a plain loop:
+// rarely entered); a match of 17..32 bytes is appended to a per-wave list in LDS instead of the match-index buffer;
+// every lane has a second accumulator `far` for the end position 17..32 ahead, which the lane takes over when its
+// step restarts it; after the 16 steps of the group a long match STARTS in, its entry is applied — best[start] +
+// score into `acc` (end position 17..31 ahead of the group's first position) or `far` (32..47).  A group of 16
+// positions runs the ordinary steps (relax5_step) unless some lane of the wave holds a pending `far` value or the
+// list holds an entry: the slow steps (relax5l_step) are the exception, and a vocabulary with a few hundred long
+// tokens encodes at the speed of one without.
+// Order of candidates (model.rs:96-108: ascending starts, strict '>', so the LONGEST token wins among equal scores):
+// a long candidate is applied out of order and replaces an equal score iff its token is longer; `far` wins ties
+// against near candidates at a restart (everything in `far` starts earlier than any near start of that position).
+// A list that fills up puts the wave's samples on P.redo_list: the host redoes exactly those with encode2_kernel.
+constexpr uint32_t kE5LongCap = 62;                         // list entries per wave and iteration
+constexpr uint32_t kE5LongBytes = 8u + kE5LongCap * 4u;     // {count, pad} + entries {lane | group << 6 | depth << 8 | rank << 16}
+constexpr uint32_t kFarCode = 0x80u;                        // winner code of a long token: kFarCode | (length - 1)
+
+__device__ __forceinline__ uint32_t e5_winner_len_m1(uint32_t code, uint32_t l) {  // near winners: the step that pushed them
+    return (code & kFarCode) ? (code & 31u) : ((l - code - 1u) & 15u);
+}
+
+template <int U>
+__device__ __forceinline__ void relax5l_step(double sv, double& acc, uint32_t& bpv, double& far, uint32_t& fbp, uint32_t& fin, double& fval) {
+    constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
+    fin = sel_u32(MU, bpv, fin);             // winner of position p0 + U is final now
+    fval = sel_f64(MU, acc, fval);           // and its score (the long matches that start there need it)
+    const double best = row_bcast_f64<U>(acc);
+    const double cur = sel_f64(MU, far, acc);          // lane U restarts on position + 16: from its long candidates
+    const uint32_t curbp = sel_u32(MU, fbp, bpv);
+    far = sel_f64(MU, -__builtin_huge_val(), far);     // `far` of lane U now stands for position + 32
+    const double cand = best + sv;                     // model.rs:98
+    const uint64_t take = __builtin_amdgcn_fcmp(cand, cur, 2 /* OGT: model.rs:101; far wins ties */);
+    asm("v_max_f64 %0, %1, %2" : "=v"(acc) : "v"(cur), "v"(cand));
+    bpv = sel_imm_u32<U>(take, curbp);
+}
+
+// the walk of group g's lanes past 16 bytes (alive: the walk matched 16 bytes and the trie goes on): appends the
+// matches of 17..32 bytes to the wave's list.  rec_x: the walk's record of depth 15.
+template <bool DROPOUT>
+__device__ __forceinline__ void e5_long_tail(__amdgpu_buffer_rsrc_t trie, const uint8_t* __restrict__ text16, uint32_t rec_x, bool alive,
+                                             uint32_t maxd, uint32_t lane, uint32_t g, uint32_t list_off, double dropout, uint64_t seed,
+                                             uint32_t s, uint32_t pg) {
+    bool more = alive && maxd > 16u;
+    if (__builtin_amdgcn_ballot_w64(more) == 0) return;  // wave-uniform: the ordinary case
+    struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t w[4]; };
+    Bytes16 b{{0u, 0u, 0u, 0u}};
+    if (more) b = *reinterpret_cast<const Bytes16*>(text16);  // text bytes 16..31 of this lane's position (the text is padded)
+    uint32_t x = rec_x;
+#pragma unroll 1
+    for (uint32_t d = 16u; d < 32u; ++d) {
+        more = more && d < maxd;
+        if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+        const uint32_t bi = d - 16u;
+        const uint32_t word = (bi & 8u) ? ((bi & 4u) ? b.w[3] : b.w[2]) : ((bi & 4u) ? b.w[1] : b.w[0]);
+        const uint32_t c = (word >> ((bi & 3u) * 8u)) & 0xFFu;
+        const uint2 rec = buf_ld8(trie, more ? ((x ^ (c << 3)) & 0xFFFFFFu) : 0u);
+        more = more && (rec.x >> 24) == c;
+        const uint32_t rank = rec.y & 0xFFFFu;
+        bool term = more && rank != 0u;
+        if (DROPOUT) {
+            if (term) term = dropout < dropout_u01(seed, s, pg, d + 1u);
+        }
+        if (term) {
+            const uint32_t slot = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)(uintptr_t)list_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot < kE5LongCap) lds_st<uint32_t>(list_off + 8u + slot * 4u, lane | (g << 6) | (d << 8) | (rank << 16));
+        }
+        x = rec.x;
+    }
+}
+
 // TGX_STAMPS=1 (diagnostic runs only): s_memtime stamps around the phases of an iteration, summed per wave
 #define E5_STAMP(i)                                                    \
     if (P.stamps) {                                                    \
@@ -179,10 +263,11 @@ __device__ __forceinline__ void e5_scores_cold(uint32_t tab, __amdgpu_buffer_rsr
         t_last = _now;                                                 \
     }
 
-template <bool DROPOUT, bool COLD, int PPL>
+template <bool DROPOUT, bool COLD, int PPL, bool LONG>
 __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void encode5_kernel(EncodeParams P, Encode5Params Q) {
+    static_assert(!LONG || PPL == 4, "the long-token build runs four positions per lane");
     extern __shared__ __align__(16) unsigned char smem[];
-    constexpr uint32_t LM = 16;
+    constexpr uint32_t LM = LONG ? 32 : 16;
     constexpr uint32_t SPAN = 16u * PPL;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t l = lane & 15u, r = lane >> 4;
@@ -208,8 +293,9 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
     uint64_t beg = 0;
     bool live = false, need_new = true;
     const double ninf = -__builtin_huge_val();
-    double acc = ninf;
-    uint32_t bpv = kNoStep;
+    double acc = ninf, far = ninf;       // LONG: `far` collects the long candidates of the position 17..32 ahead
+    uint32_t bpv = kNoStep, fbp = kFarCode;
+    bool redo = false;                   // LONG: this row's sample is on the redo list already
     uint32_t wn[4 * PPL + 1];
     uint32_t pk = 0, pk_j = 0;
     bool pk_dirty = false;
@@ -221,6 +307,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
     const uint32_t wbase_off = lds0 + Q.idx_off + wave * (PPL * kE5GroupBytes);  // this wave's match-index buffers, LDS byte offset
     const uint32_t wr_off = wbase_off + r * kE5RowStride + l * 2u;                // ... this lane's entries as a walker, column bits clear
     const uint32_t col_off = wbase_off + my_col;                                  // ... and its 32 contiguous bytes as the relaxing lane
+    const uint32_t list_off = lds0 + Q.list_off + wave * ((kE5LongBytes + 15u) & ~15u);  // LONG: this wave's list of long matches
     uint64_t seg[5] = {0, 0, 0, 0, 0};
     uint64_t t_last = P.stamps ? (uint64_t)__builtin_amdgcn_s_memtime() : 0;
     uint32_t iters = 0;
@@ -251,6 +338,11 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             acc = (l == 0u) ? 0.0 : ninf;
             bpv = kNoStep;
             pk_dirty = false;
+            if (LONG) {
+                far = ninf;
+                fbp = kFarCode;
+                redo = false;
+            }
         }
         const bool fresh_row = need_new;
         need_new = false;
@@ -283,6 +375,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             mine[0] = make_uint4(0, 0, 0, 0);
             mine[1] = make_uint4(0, 0, 0, 0);
         }
+        if (LONG && lane == 0u) lds_st<uint32_t>(list_off, 0u);  // this iteration's long matches
         __builtin_amdgcn_wave_barrier();
         E5_STAMP(1)  // text window, reset
 
@@ -308,7 +401,13 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
             WalkCtx<PPL> W{trie_b, s, l32, P.dropout, P.seed};
-            Walk5<DROPOUT, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
+            Walk5<DROPOUT, LONG, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
+        }
+        if (LONG) {
+#pragma unroll
+            for (int g = 0; g < PPL; ++g)
+                e5_long_tail<DROPOUT>(trie_b, P.text + (live ? beg + pg[g] + 16u : 0), rec[g].x, alive[g], maxd[g], lane, (uint32_t)g, list_off,
+                                      P.dropout, P.seed, s, pg[g]);
         }
         __builtin_amdgcn_wave_barrier();
         E5_STAMP(2)  // walk
@@ -341,6 +440,67 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
                 uint32_t (&nw)[8] = (g & 1) ? iw : iwn;
                 fin[g] = kNoStep;
                 uint32_t fhi = 0xFFF00000u;
+                bool slow = false;   // LONG: some lane holds a long candidate, or a long match waits in the list (wave-uniform)
+                uint32_t n_list = 0;
+                if (LONG) {
+                    n_list = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld<uint32_t>(list_off));
+                    slow = n_list != 0u || __builtin_amdgcn_ballot_w64((uint32_t)((uint64_t)__double_as_longlong(far) >> 32) != 0xFFF00000u) != 0;
+                }
+                if (LONG && slow) {
+                    // ---- the steps with the second accumulator, then the long matches that start in this group
+                    auto rank_of = [&](int u) { return (u & 1) ? (cw[u >> 1] >> 16) : (cw[u >> 1] & 0xFFFFu); };
+                    double fval = ninf;
+                    relax5l_step<0>(e5_score_one<COLD>(lds0, cold_values, rank_of(0), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<1>(e5_score_one<COLD>(lds0, cold_values, rank_of(1), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<2>(e5_score_one<COLD>(lds0, cold_values, rank_of(2), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<3>(e5_score_one<COLD>(lds0, cold_values, rank_of(3), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<4>(e5_score_one<COLD>(lds0, cold_values, rank_of(4), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<5>(e5_score_one<COLD>(lds0, cold_values, rank_of(5), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<6>(e5_score_one<COLD>(lds0, cold_values, rank_of(6), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<7>(e5_score_one<COLD>(lds0, cold_values, rank_of(7), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<8>(e5_score_one<COLD>(lds0, cold_values, rank_of(8), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<9>(e5_score_one<COLD>(lds0, cold_values, rank_of(9), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<10>(e5_score_one<COLD>(lds0, cold_values, rank_of(10), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<11>(e5_score_one<COLD>(lds0, cold_values, rank_of(11), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<12>(e5_score_one<COLD>(lds0, cold_values, rank_of(12), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<13>(e5_score_one<COLD>(lds0, cold_values, rank_of(13), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<14>(e5_score_one<COLD>(lds0, cold_values, rank_of(14), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    relax5l_step<15>(e5_score_one<COLD>(lds0, cold_values, rank_of(15), hot_bytes), acc, bpv, far, fbp, fin[g], fval);
+                    // After the 16 steps lane j of a row accumulates position + 16 + j in `acc` and + 32 + j in `far`
+                    // (positions counted from this group's first); entry (start lane, depth d) is the token of d + 1
+                    // bytes that starts at the start lane's position of group eg: it ends 17..47 positions on.
+                    const uint32_t cnt = n_list < kE5LongCap ? n_list : kE5LongCap;
+#pragma unroll 1
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld<uint32_t>(list_off + 8u + i * 4u));
+                        if (((e >> 6) & 3u) != (uint32_t)g) continue;  // wave-uniform: a match that starts in another group
+                        const uint32_t src = e & 63u, d = (e >> 8) & 31u;
+                        const double score = e5_score_one<COLD>(lds0, cold_values, e >> 16, hot_bytes);
+                        const double cand = readlane_f64(fval, src) + score;  // model.rs:98
+                        const uint32_t tt = (src & 15u) + d + 1u;             // end position - this group's first: 17 .. 47
+                        const bool mine = (lane >> 4) == (src >> 4) && l == (tt & 15u);
+                        const bool to_far = tt >= 32u;
+                        const double curv = to_far ? far : acc;
+                        const uint32_t curc = to_far ? fbp : bpv;
+                        // longer token = earlier start: it wins an equal score; a near winner is always shorter
+                        const bool longer = !(curc & kFarCode) || d > (curc & 31u);
+                        const bool take = mine && (cand > curv || (cand == curv && longer));
+                        if (take && to_far) {
+                            far = cand;
+                            fbp = kFarCode | d;
+                        }
+                        if (take && !to_far) {
+                            acc = cand;
+                            bpv = kFarCode | d;
+                        }
+                    }
+                    reached[g] = fval > ninf;
+                    if (g + 1 < PPL) {  // what the ordinary steps of the next group expect to find requested
+                        load_iw(g + 1, nw);
+                        if (!COLD) e5_scores_issue<4>(lds0, nw, 0, sa);
+                    }
+                    continue;
+                }
                 if (COLD) {
                     // both halves' cold values are requested before the first step: the loads sit behind branches, so
                     // the compiler waits for all of them at the first use — one exposed L2 round trip per group, not two
@@ -405,7 +565,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
 #pragma unroll
         for (int g = 0; g < PPL; ++g)
             if (live && pg[g] >= 1u && pg[g] <= n) {
-                const uint32_t b = reached[g] ? ((l - fin[g] - 1u) & 15u) : 0xFFu;
+                const uint32_t b = reached[g] ? (LONG ? e5_winner_len_m1(fin[g], l) : ((l - fin[g] - 1u) & 15u)) : 0xFFu;
                 const uint32_t j = pg[g] - 1u, kq = (j >> 4) & 3u;
                 pk = (kq == 0u) ? b : (pk | (b << (8u * kq)));
                 pk_j = j;
@@ -415,6 +575,13 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
                     pk_dirty = false;
                 }
             }
+        if (LONG) {  // a list that filled up dropped matches, whichever row they belonged to: encode2_kernel redoes these samples
+            const uint32_t n_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld<uint32_t>(list_off));
+            if (n_all > kE5LongCap) {
+                if (live && !redo && l == 0u) P.redo_list[atomicAdd(P.redo_count, 1ULL)] = s;
+                redo = true;
+            }
+        }
         if (live && n - p0 < SPAN && pk_dirty) {
             __builtin_nontemporal_store(pk, reinterpret_cast<uint32_t*>(bpw + (bp8_perm(pk_j) & ~3u)));
             pk_dirty = false;
@@ -719,7 +886,7 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
             WalkCtx<1> W{trie_b, s, l32, P.dropout, P.seed};
-            Walk5<DROPOUT, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
+            Walk5<DROPOUT, false, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0u) lds_store(&ctrl->walk_done[slot], t + 1u);
         }
@@ -727,20 +894,27 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
 }
 
 typedef void (*encode5_fn)(EncodeParams, Encode5Params);
-static encode5_fn pick_encode5(bool dropout, bool cold, int ppl) {
-    if (cold) {
-        if (ppl == 1) return dropout ? encode5_kernel<true, true, 1> : encode5_kernel<false, true, 1>;
-        if (ppl == 2) return dropout ? encode5_kernel<true, true, 2> : encode5_kernel<false, true, 2>;
-        return dropout ? encode5_kernel<true, true, 4> : encode5_kernel<false, true, 4>;
+static encode5_fn pick_encode5(bool dropout, bool cold, int ppl, bool long_tokens) {
+    if (long_tokens) {  // tokens of 17..32 bytes: four positions per lane only
+        if (cold) return dropout ? encode5_kernel<true, true, 4, true> : encode5_kernel<false, true, 4, true>;
+        return dropout ? encode5_kernel<true, false, 4, true> : encode5_kernel<false, false, 4, true>;
     }
-    if (ppl == 1) return dropout ? encode5_kernel<true, false, 1> : encode5_kernel<false, false, 1>;
-    if (ppl == 2) return dropout ? encode5_kernel<true, false, 2> : encode5_kernel<false, false, 2>;
-    return dropout ? encode5_kernel<true, false, 4> : encode5_kernel<false, false, 4>;
+    if (cold) {
+        if (ppl == 1) return dropout ? encode5_kernel<true, true, 1, false> : encode5_kernel<false, true, 1, false>;
+        if (ppl == 2) return dropout ? encode5_kernel<true, true, 2, false> : encode5_kernel<false, true, 2, false>;
+        return dropout ? encode5_kernel<true, true, 4, false> : encode5_kernel<false, true, 4, false>;
+    }
+    if (ppl == 1) return dropout ? encode5_kernel<true, false, 1, false> : encode5_kernel<false, false, 1, false>;
+    if (ppl == 2) return dropout ? encode5_kernel<true, false, 2, false> : encode5_kernel<false, false, 2, false>;
+    return dropout ? encode5_kernel<true, false, 4, false> : encode5_kernel<false, false, 4, false>;
 }
 
-// LDS of one block of `waves` waves: score table (-inf and n_hot values), root records, match indices
-uint32_t encode5_lds_layout(uint32_t n_hot, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off) {
-    const uint32_t score_bytes = 8u * (n_hot + 1u);
+// LDS of one block of `waves` waves: score table (-inf and n_hot values), the waves' lists of long matches (LONG
+// builds), root records, match indices
+uint32_t encode5_lds_layout(uint32_t n_hot, bool long_tokens, int waves, int ppl, uint32_t* list_off, uint32_t* root_off, uint32_t* idx_off) {
+    const uint32_t lo = (8u * (n_hot + 1u) + 15u) & ~15u;
+    const uint32_t score_bytes = lo + (long_tokens ? (uint32_t)waves * ((kE5LongBytes + 15u) & ~15u) : 0u);
+    if (list_off) *list_off = lo;
     const uint32_t ro = (score_bytes + 15u) & ~15u;
     const uint32_t io = (ro + 2048u + 511u) & ~511u;  // 512-byte aligned: see kE5RowStride
     if (root_off) *root_off = ro;
@@ -748,14 +922,14 @@ uint32_t encode5_lds_layout(uint32_t n_hot, int waves, int ppl, uint32_t* root_o
     return io + (uint32_t)waves * (uint32_t)ppl * kE5GroupBytes;
 }
 // the largest table that leaves a block of `waves` waves within `budget` bytes of LDS
-uint32_t encode5_max_hot(int waves, int ppl, uint32_t budget) {
-    const uint32_t fixed = encode5_lds_layout(0u, waves, ppl, nullptr, nullptr) + 512u;  // alignment slack
+uint32_t encode5_max_hot(bool long_tokens, int waves, int ppl, uint32_t budget) {
+    const uint32_t fixed = encode5_lds_layout(0u, long_tokens, waves, ppl, nullptr, nullptr, nullptr) + 512u;  // alignment slack
     return budget > fixed + 64u ? (budget - fixed) / 8u : 0u;
 }
 
-hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out) {
+hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, bool long_tokens, int* out) {
     hipFuncAttributes attr;
-    hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(pick_encode5(dropout, cold, ppl)));
+    hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(pick_encode5(dropout, cold, ppl, long_tokens)));
     if (e != hipSuccess) return e;
     const int regs = (attr.numRegs + 7) & ~7;
     *out = regs > 0 ? (512 / regs > 8 ? 8 : 512 / regs) : 8;
@@ -790,10 +964,10 @@ hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uin
     return hipGetLastError();
 }
 
-hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
-    const uint32_t lds = encode5_lds_layout(q.n_hot, waves, ppl, &q.root_off, &q.idx_off);
-    if (lds > 160u * 1024u || q.n_hot > q.n_values || (!cold && q.n_hot != q.n_values)) return hipErrorInvalidValue;
-    encode5_fn fn = pick_encode5(p.dropout > 0.0, cold, ppl);
+hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, bool long_tokens, int waves, uint32_t blocks, hipStream_t stream) {
+    const uint32_t lds = encode5_lds_layout(q.n_hot, long_tokens, waves, ppl, &q.list_off, &q.root_off, &q.idx_off);
+    if (lds > 160u * 1024u || q.n_hot > q.n_values || (!cold && q.n_hot != q.n_values) || (long_tokens && ppl != 4)) return hipErrorInvalidValue;
+    encode5_fn fn = pick_encode5(p.dropout > 0.0, cold, ppl, long_tokens);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), lds, stream, p, q);

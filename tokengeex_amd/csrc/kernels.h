@@ -42,7 +42,7 @@ struct Encode5Params {
     uint32_t n_values;              // distinct score values of the vocabulary (<= 65 535)
     uint32_t n_hot;                 // ranks 1..n_hot are copied into the block's LDS; COLD builds read the rest from `values`
     uint32_t claim_chunk;           // consecutive samples of the order a row claims per atomic (>= 1)
-    uint32_t root_off, idx_off;     // LDS layout (set by the launcher)
+    uint32_t list_off, root_off, idx_off;  // LDS layout (set by the launcher)
     uint32_t ctrl_off, ring_off, ring_slots;  // encode6_kernel: control words, ring of match-index buffers
 };
 
@@ -150,13 +150,13 @@ hipError_t encode4_waves_per_simd(bool dropout, int ppl, bool root, int* out);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream);
 uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
-uint32_t encode5_lds_layout(uint32_t n_hot, int waves, int ppl, uint32_t* root_off, uint32_t* idx_off);
-uint32_t encode5_max_hot(int waves, int ppl, uint32_t budget);
-hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, int* out);
+uint32_t encode5_lds_layout(uint32_t n_hot, bool long_tokens, int waves, int ppl, uint32_t* list_off, uint32_t* root_off, uint32_t* idx_off);
+uint32_t encode5_max_hot(bool long_tokens, int waves, int ppl, uint32_t budget);
+hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, bool long_tokens, int* out);
 uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
 uint32_t encode6_max_hot(uint32_t budget);
 hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream);
-hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream);
+hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, bool long_tokens, int waves, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip
 hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream);
 hipError_t launch_encode4l(const EncodeParams& p, uint32_t num_cus, hipStream_t stream);  // encode4l.hip

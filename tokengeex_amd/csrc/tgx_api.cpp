@@ -369,13 +369,16 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     const bool use4 = m->lm <= 16 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
     // vocabularies with tokens of 17..32 bytes (after `merge`): two samples per wave (encode2.hip)
     const bool use2 = !use4 && m->lm <= 32 && m->scores_finite && m->d_tokhash && !(force && strcmp(force, "fused") == 0);
-    // encode5_kernel / encode6_kernel (8-byte records with child masks, match indices = ranks of score values, the
-    // hottest values in LDS and the rest read from L2 by the relaxing lane) for every vocabulary of tokens <= 16 bytes
-    // with finite scores and at most 65 535 distinct score values — round 3: that includes vocabularies in which
-    // every token has its own score (after an M-step or merge: any trained vocabulary).  encode4_kernel remains for
-    // more distinct values than that (the 500 000-entry stages of prune).  TGX_PATH=rows4 / rows5 force either
-    // kernel (A/B timing, tests of both paths).
-    const bool use5 = use4 && m->have_trie8 && !(force && strcmp(force, "rows4") == 0);
+    // encode5_kernel / encode6_kernel (8-byte label-checked records, match indices = ranks of score values, the
+    // hottest values in LDS and the rest read from L2 by the relaxing lanes) for every vocabulary with finite scores
+    // and at most 65 535 distinct score values — round 3: that includes vocabularies in which every token has its own
+    // score (after an M-step or merge: any trained vocabulary) and vocabularies with tokens of 17..32 bytes (after
+    // `merge`: the LONG build of encode5_kernel).  encode4_kernel / encode4l_kernel remain for more distinct values
+    // than that (the 500 000-entry stages of prune).  TGX_PATH=rows4 / rows5 / rows2 force a kernel (A/B timing,
+    // tests of every path).
+    const bool long_tokens = m->lm > 16;
+    const bool use5 = (use4 || use2) && m->have_trie8 &&
+                      !(force && (strcmp(force, "rows4") == 0 || strcmp(force, "rows2") == 0 || strcmp(force, "rows4l") == 0));
     if (debug_on())
         fprintf(stderr, "[tgx] encode: S=%llu N=%llu lm=%u path=%s slots=%zu root_base=%u values=%u\n",
                 (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? (use5 ? "rows5" : "rows4") : (use2 ? "rows2" : "fused"),
@@ -386,19 +389,26 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         // number of distinct score values (1 GiB of the bench corpus, profiles/r03):
         //   * four positions per lane (the four staggered walks of a lane hide most of each other's gather latency,
         //     encode5.hip: Walk5) with EVERY value in LDS: up to ~3 700 values, 11.0 ms;
+        //   * the same with 15 / 14 / 13 waves, every value in LDS: up to ~4 700 / 5 700 / 6 800 values, 11.4 - 12.3 ms;
         //   * two positions per lane, every value in LDS: up to ~11 900 values — the generate-style vocabularies
         //     of SURVEY.md 8(d), 9 652 values at 32 000 entries, 10 569 at 65 536 —, 12.7 ms;
         //   * four positions per lane with the ~3 700 hottest values in LDS and the others read from L2 by the
         //     relaxing lanes (COLD builds; every token its own score: after an M-step or merge), 14.2 - 14.6 ms.
         // Fewer waves when the batch has fewer samples than the chip has rows, so that they spread over the CUs.
-        int ppl = 4, bpc = 1;
+        // Tokens of 17..32 bytes: the LONG build (four positions per lane, a list of long matches per wave).
+        int ppl = 4, bpc = 1, hot_waves = 16;  // hot_waves: the most waves beside which every value fits (four positions per lane)
         {
             int ps4 = 0;
-            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, 4, &ps4));
-            const int w4 = std::min(16, ps4 * 4);
-            if (m->n_values > tgx::encode5_max_hot(w4, 4, 160u * 1024u) && m->n_values <= tgx::encode5_max_hot(16, 2, 160u * 1024u)) ppl = 2;
+            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, 4, long_tokens, &ps4));
+            hot_waves = std::min(16, ps4 * 4);
+            const int least = long_tokens ? 12 : 13;  // (the long-token build has no two-positions-per-lane variant to fall to)
+            while (hot_waves >= least && m->n_values > tgx::encode5_max_hot(long_tokens, hot_waves, 4, 160u * 1024u)) hot_waves--;
+            if (hot_waves < least) {
+                hot_waves = 0;  // not with four positions per lane
+                if (!long_tokens && m->n_values <= tgx::encode5_max_hot(false, 16, 2, 160u * 1024u)) ppl = 2;
+            }
         }
-        if (const char* e = knob("TGX_PPL")) {
+        if (const char* e = long_tokens ? nullptr : knob("TGX_PPL")) {
             const int v = atoi(e);
             if (v == 1 || v == 2 || v == 4) {
                 ppl = v;
@@ -412,11 +422,12 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         const uint32_t budget = 160u * 1024u / (uint32_t)bpc;
         bool cold = false;
         int per_simd = 0;
-        HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, ppl, &per_simd));
+        HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, ppl, long_tokens, &per_simd));
         int waves = std::min(16, (per_simd / bpc) * 4);
-        if (m->n_values > tgx::encode5_max_hot(waves, ppl, budget)) {
+        if (ppl == 4 && bpc == 1 && hot_waves > 0) waves = std::min(waves, hot_waves);
+        if (m->n_values > tgx::encode5_max_hot(long_tokens, waves, ppl, budget)) {
             cold = true;
-            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, true, ppl, &per_simd));
+            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, true, ppl, long_tokens, &per_simd));
             waves = std::min(16, (per_simd / bpc) * 4);
         }
         {
@@ -427,8 +438,8 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             const int v = atoi(e);
             if (v >= 1 && v <= 16) waves = v;
         }
-        while (waves > 1 && tgx::encode5_max_hot(waves, ppl, budget) < 16u) waves--;
-        uint32_t n_hot = std::min(m->n_values, tgx::encode5_max_hot(waves, ppl, budget));
+        while (waves > 1 && tgx::encode5_max_hot(long_tokens, waves, ppl, budget) < 16u) waves--;
+        uint32_t n_hot = std::min(m->n_values, tgx::encode5_max_hot(long_tokens, waves, ppl, budget));
         if (const char* e = knob("TGX_E5_HOT")) {  // tests of the COLD builds (a small LDS copy), table-size sweeps
             const int v = atoi(e);
             if (v >= 0) n_hot = std::min(n_hot, (uint32_t)v);
@@ -470,7 +481,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         const bool cold6 = n_hot6 < m->n_values;
         uint64_t n_long = 0;
-        if (c->n_samples) {
+        if (c->n_samples && !long_tokens) {  // (encode6_kernel walks 16 bytes)
             const auto count_ge = [&](uint64_t thr) {  // h_sorted_len descends: the long samples are a prefix of the order
                 return (uint64_t)(std::partition_point(c->h_sorted_len.begin(), c->h_sorted_len.end(),
                                                        [thr](uint32_t len) { return len >= thr; }) - c->h_sorted_len.begin());
@@ -527,7 +538,12 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         time_begin(m, "encode5_kernel");
         {
-            const hipError_t le = tgx::launch_encode5(p, q, cold, ppl, waves, blocks5, m->stream);
+            if (long_tokens) {  // samples whose wave ran out of list entries for long matches go to encode2_kernel
+                p.redo_count = m->d_ctrl + 6;
+                p.redo_list = c->d_counts;  // free until the trace writes the token counts
+                HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
+            }
+            const hipError_t le = tgx::launch_encode5(p, q, cold, ppl, long_tokens, waves, blocks5, m->stream);
             if (le != hipSuccess) {
                 if (d_stamps5) {
                     (void)hipStreamSynchronize(m->stream);
@@ -552,12 +568,29 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             fprintf(stderr, "[tgx] encode5 stamps (s_memtime ticks per wave-iteration, %zu waves x ppl %d, %.0f iterations): switch %.0f  text+reset %.0f  walk %.0f  relax %.0f  store %.0f\n",
                     n_stamp_waves5, ppl, iters, sum[0] / iters, sum[1] / iters, sum[2] / iters, sum[3] / iters, sum[4] / iters);
         }
+        if (long_tokens) {
+            unsigned long long n_redo = 0;
+            HIP_TRY(hipMemcpyAsync(&n_redo, m->d_ctrl + 6, 8, hipMemcpyDeviceToHost, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (n_redo > c->n_samples) return fail(TGX_ERR_DEVICE, "redo list longer than the batch");
+            m->last_redo_samples = n_redo;
+            if (n_redo) {
+                tgx::EncodeParams q2 = p;
+                q2.order = c->d_counts;
+                q2.n_samples = n_redo;
+                HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue
+                time_begin(m, "encode2_kernel");
+                HIP_TRY(tgx::launch_encode2(q2, (uint32_t)m->num_cus, true, m->stream));
+                time_end(m);
+            }
+        }
         p.order = c->d_order;
         p.n_samples = c->n_samples;
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
-        time_begin(m, "trace_kernel");
-        HIP_TRY(tgx::launch_trace(p, blocks_t, m->stream));
+        time_begin(m, long_tokens ? "trace32_kernel" : "trace_kernel");
+        if (long_tokens) HIP_TRY(tgx::launch_trace32(p, blocks_t, true, m->stream));
+        else HIP_TRY(tgx::launch_trace(p, blocks_t, m->stream));
         time_end(m);
     } else if (use4) {
         // Vocabularies without 8-byte records (more than 65 535 distinct score values): round 1's kernel over the
@@ -799,7 +832,7 @@ static tgx_status ensure_encode_tables(tgx_model* m) {
     // the bytes -> id table and the 8-byte records are independent: the first is built on a second host thread
     // while this one builds the second (each ~50 ms at 500 000 tokens)
     const bool want_hash = m->lm <= 32 && m->scores_finite;
-    const bool want_trie8 = m->lm <= 16 && m->scores_finite && m->flat.table.size() <= tgx::kTrie8MaxSlots;
+    const bool want_trie8 = m->lm <= 32 && m->scores_finite && m->flat.table.size() <= tgx::kTrie8MaxSlots;
     std::thread hash_builder;
     if (want_hash && !m->tokhash_host_built)
         hash_builder = std::thread([m]() { tgx::build_tok_hash(m->vocab_bytes.data(), m->vocab_offs.data(), m->vocab_size, &m->tokhash); });
