@@ -150,14 +150,18 @@ def test_long_sample_kernel_walkers_and_relaxer(monkeypatch, threshold):
     assert e.value.sample == 1 and str(e.value) == "no path to position 6201/6201"
 
 
-@pytest.mark.parametrize("hot", ["2000", "300", "0"])
-def test_long_sample_kernel_with_values_outside_its_lds_copy(monkeypatch, hot):
-    """encode6_kernel's relaxing wave with score values outside the LDS copy: read from L2 a quarter group ahead
-    of the steps that use them; nothing is redone."""
+@pytest.mark.parametrize("hot,pool", [("2000", None), ("300", None), ("0", None), ("2000", "8"), ("300", "0"), ("0", "192"), ("4000", "16")])
+def test_long_sample_kernel_with_values_outside_its_lds_copy(monkeypatch, hot, pool):
+    """encode6_kernel with score values outside the LDS copy: the walkers fetch them into the pool entries of their
+    ring slot (round 3: the relaxer finds them in LDS), and what a full pool leaves behind the relaxer reads from L2
+    a quarter group ahead of the steps that use them — small copies and small pools (none at all: round 2's path)
+    force the second, the default pool the first; nothing is redone."""
     rng = np.random.default_rng(21)
     flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 8000, 16, seed_offset=54, max_len=30000)
     scores = _distinct_scores(scores, rng)
     monkeypatch.setenv("TGX_E5_HOT", hot)
+    if pool is not None:
+        monkeypatch.setenv("TGX_E6_POOL", pool)
     monkeypatch.setenv("TGX_LONG_THRESHOLD", "2000")
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
     assert_same_encoding(nat, ora, flat, offs)

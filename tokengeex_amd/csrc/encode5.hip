@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -72,6 +74,34 @@ struct WalkCtx {
     uint64_t seed;
 };
 
+// RES walks (the walker waves of encode6_kernel, COLD builds): a match whose value is not in the block's LDS copy is
+// RESOLVED by the walker — it reads the value from the table in L2 and parks it in a pool entry of its ring slot, the
+// match index becomes that entry's — so the relaxer, whose steps are the sample's serial chain, finds every value in
+// LDS.  The load is issued at the depth that finds the match, ahead of the walk's next gather, and completed at the
+// next depth (vector loads return in order: by then it has arrived).  Indices: 0 = "no token", 1 .. shift = pool
+// entries, rank + shift = the value of that rank (in the LDS copy iff <= hot_max).  A pool that is full leaves the
+// rank in place: the relaxer reads those from L2 itself, as before.
+struct Res5 {
+    __amdgpu_buffer_rsrc_t cold;  // the value table from rank n_hot + 1 on
+    uint32_t tab;                 // LDS byte offset of the block's table
+    uint32_t shift, hot_max;      // see above
+    uint32_t used_off;            // LDS byte offset of the slot's count of pool entries handed out
+    uint32_t first, cap;          // the slot's pool entries: indices first .. first + cap - 1
+    bool pend;                    // per lane: a cold match of the depth before awaits its value
+    uint32_t pend_addr;
+    double pend_val;
+    __device__ __forceinline__ void complete() {
+        if (pend) {
+            const uint32_t e = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t*)(uintptr_t)used_off, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (e < cap) {
+                lds_st<double>(tab + 8u * (first + e), pend_val);
+                lds_st<uint16_t>(pend_addr, (uint16_t)(first + e));
+            }
+        }
+        pend = false;
+    }
+};
+
 // ---- the trie walks of a lane (PPL start positions), unrolled over the depth D by template recursion (with
 // its early exit inside, hipcc's unroller gives up on the plain loop and the text bytes end up selected by
 // v_cndmask chains).  The PPL walks are STAGGERED: a level consumes the record of walk g and at once requests
@@ -84,12 +114,13 @@ struct WalkCtx {
 // not exist — and the stagger would be lost; lanes reading record 0 cost the texture path next to nothing,
 // profiles/r03/d_gather3_dead_lanes.txt.  For the same reason the hottest slots are NOT read from an LDS copy:
 // tried, 2 % at best, a step still waits for its slowest lane, which goes to L2.)
-template <bool DROPOUT, bool LONG, int PPL, int D>
+template <bool DROPOUT, bool LONG, bool RES, int PPL, int D>
 struct Walk5 {
     // rec[g], c[g]: record and text byte of depth D of walk g (the load may still be in flight)
-    static __device__ __forceinline__ void run(const WalkCtx<PPL>& W, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
+    static __device__ __forceinline__ void run(const WalkCtx<PPL>& W, Res5& R, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
                                                const uint32_t (&pg)[PPL], const uint32_t (&wlane)[PPL], bool (&alive)[PPL],
                                                uint2 (&rec)[PPL], uint32_t (&c)[PPL]) {
+        static_assert(!RES || PPL == 1, "resolving walks keep one pending value per lane");
         constexpr int d = D;
         bool any = false;
 #pragma unroll
@@ -101,7 +132,19 @@ struct Walk5 {
             if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
                 if (term && d >= 1) term = W.dropout < dropout_u01(W.seed, W.s, pg[g], (uint32_t)d + 1u);
             }
-            if (term) lds_st<uint16_t>(wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u), (uint16_t)rank);
+            if (RES) {
+                if (D > 0) R.complete();  // the cold match of the depth before: its value was requested ahead of this depth's record
+                const uint32_t addr = wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u);
+                const uint32_t idx = rank + R.shift;
+                if (term) lds_st<uint16_t>(addr, (uint16_t)idx);
+                R.pend = term && idx > R.hot_max && R.cap != 0u;
+                if (R.pend) {
+                    R.pend_val = buf_ld_f64(R.cold, (idx - R.hot_max - 1u) << 3);
+                    R.pend_addr = addr;
+                }
+            } else {
+                if (term) lds_st<uint16_t>(wlane[g] | ((W.l32 + 32u * (uint32_t)d) & 0x1E0u), (uint16_t)rank);
+            }
             // this walk's next record
             if (D + 1 < 16) {
                 constexpr int e = D + 1 < 16 ? D + 1 : 15;
@@ -114,15 +157,20 @@ struct Walk5 {
             }  // LONG: alive[g] says whether the walk goes on past 16 bytes (rec[g] is its record of depth 15): e5_long_tail
             any = any || alive[g];
         }
-        if (__builtin_amdgcn_ballot_w64(any) == 0) return;
-        Walk5<DROPOUT, LONG, PPL, D + 1>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
+        if (__builtin_amdgcn_ballot_w64(any) == 0) {
+            if (RES) R.complete();
+            return;
+        }
+        Walk5<DROPOUT, LONG, RES, PPL, D + 1>::run(W, R, bytes, maxd, pg, wlane, alive, rec, c);
     }
 };
-template <bool DROPOUT, bool LONG, int PPL>
-struct Walk5<DROPOUT, LONG, PPL, 16> {
-    static __device__ __forceinline__ void run(const WalkCtx<PPL>&, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL],
+template <bool DROPOUT, bool LONG, bool RES, int PPL>
+struct Walk5<DROPOUT, LONG, RES, PPL, 16> {
+    static __device__ __forceinline__ void run(const WalkCtx<PPL>&, Res5& R, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL],
                                                const uint32_t (&)[PPL], const uint32_t (&)[PPL], bool (&)[PPL], uint2 (&)[PPL],
-                                               uint32_t (&)[PPL]) {}
+                                               uint32_t (&)[PPL]) {
+        if (RES) R.complete();
+    }
 };
 
 // The score values of N consecutive steps (from step `first`) of a lane, whose sixteen match indices are the 16-bit
@@ -401,7 +449,8 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void enc
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
             WalkCtx<PPL> W{trie_b, s, l32, P.dropout, P.seed};
-            Walk5<DROPOUT, LONG, PPL, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
+            Res5 no_res{};
+            Walk5<DROPOUT, LONG, false, PPL, 0>::run(W, no_res, bytes, maxd, pg, wlane, alive, rec, c);
         }
         if (LONG) {
 #pragma unroll
@@ -639,6 +688,8 @@ struct E6Ctrl {
     uint32_t pad_;
     uint32_t walk_done[8];
     uint32_t ack[4];      // walker j -> relaxer: the epoch whose (s, n, beg, trip0) it has read
+    uint32_t pool_used[8];  // COLD builds: pool entries of ring slot i handed out by its walker (Res5)
+    uint32_t pad2_[4];
 };
 constexpr uint32_t kE6Done = 0xFFFFFFFFu;
 
@@ -671,12 +722,16 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
     const __amdgpu_buffer_rsrc_t trie_b = make_rsrc(Q.trie8, Q.trie_bytes);
     const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);  // LDS byte offset of the dynamic LDS (0 here)
     double* const score_tab = reinterpret_cast<double*>(smem);
-    const uint32_t hot_bytes = 8u * (Q.n_hot + 1u);
-    const __amdgpu_buffer_rsrc_t values = make_rsrc(reinterpret_cast<const unsigned char*>(Q.values) + hot_bytes, 8u * (Q.n_values - Q.n_hot));  // ranks beyond the LDS copy
+    // LDS table: entry 0 = -inf ("no token"), COLD builds: 4 * G * Q.pool pool entries (Res5), then the n_hot hottest values
+    const uint32_t shift = COLD ? 4u * G * Q.pool : 0u;
+    const uint32_t hot_bytes = 8u * (1u + shift + Q.n_hot);
+    const __amdgpu_buffer_rsrc_t values = make_rsrc(reinterpret_cast<const unsigned char*>(Q.values) + 8u * (Q.n_hot + 1u), 8u * (Q.n_values - Q.n_hot));  // ranks beyond the LDS copy
     const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
     E6Ctrl* const ctrl_all = reinterpret_cast<E6Ctrl*>(smem + Q.ctrl_off);
     {
-        for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = Q.values[i];
+        if (threadIdx.x == 0u) score_tab[0] = Q.values[0];
+        for (uint32_t i = threadIdx.x; i < shift; i += blockDim.x) score_tab[1u + i] = Q.values[0];
+        for (uint32_t i = threadIdx.x; i < Q.n_hot; i += blockDim.x) score_tab[1u + shift + i] = Q.values[1u + i];
         uint2* rw = reinterpret_cast<uint2*>(smem + Q.root_off);
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
         uint32_t* cw = reinterpret_cast<uint32_t*>(ctrl_all);
@@ -759,39 +814,49 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
             const uint32_t bpv_in = bpv;
             uint32_t fin[4];
             bool reached[4];
-            uint32_t iwa[8], iwb[8];
-            double sva[4], svb[4];
-            load_iw(0, iwa);
-            e6_load_quarter<COLD>(lds0, values, hot_bytes, iwa, 0, sva);
+            // COLD builds: the walkers have moved the trip's cold values into the slot's pool (Res5) unless the pool ran
+            // out — only then (or without a pool) the steps run on the variant that reads values from L2, whose
+            // clamp-and-branch per entry costs the chain ~1.7x even when nothing is cold.
+            auto relax_trip = [&](auto cold_tag) {
+                constexpr bool C = decltype(cold_tag)::value;
+                uint32_t iwa[8], iwb[8];
+                double sva[4], svb[4];
+                load_iw(0, iwa);
+                e6_load_quarter<C>(lds0, values, hot_bytes, iwa, 0, sva);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint32_t (&iw)[8] = (g & 1) ? iwb : iwa;
-                uint32_t (&iwn)[8] = (g & 1) ? iwa : iwb;
-                fin[g] = kNoStep;
-                uint32_t fhi = 0xFFF00000u;
-                e6_load_quarter<COLD>(lds0, values, hot_bytes, iw, 1, svb);
-                if (g < 3) load_iw(g + 1, iwn);
-                relax5_step<0>(sva[0], acc, bpv, fin[g], fhi);
-                relax5_step<1>(sva[1], acc, bpv, fin[g], fhi);
-                relax5_step<2>(sva[2], acc, bpv, fin[g], fhi);
-                relax5_step<3>(sva[3], acc, bpv, fin[g], fhi);
-                e6_load_quarter<COLD>(lds0, values, hot_bytes, iw, 2, sva);
-                relax5_step<4>(svb[0], acc, bpv, fin[g], fhi);
-                relax5_step<5>(svb[1], acc, bpv, fin[g], fhi);
-                relax5_step<6>(svb[2], acc, bpv, fin[g], fhi);
-                relax5_step<7>(svb[3], acc, bpv, fin[g], fhi);
-                e6_load_quarter<COLD>(lds0, values, hot_bytes, iw, 3, svb);
-                relax5_step<8>(sva[0], acc, bpv, fin[g], fhi);
-                relax5_step<9>(sva[1], acc, bpv, fin[g], fhi);
-                relax5_step<10>(sva[2], acc, bpv, fin[g], fhi);
-                relax5_step<11>(sva[3], acc, bpv, fin[g], fhi);
-                if (g < 3) e6_load_quarter<COLD>(lds0, values, hot_bytes, iwn, 0, sva);
-                relax5_step<12>(svb[0], acc, bpv, fin[g], fhi);
-                relax5_step<13>(svb[1], acc, bpv, fin[g], fhi);
-                relax5_step<14>(svb[2], acc, bpv, fin[g], fhi);
-                relax5_step<15>(svb[3], acc, bpv, fin[g], fhi);
-                reached[g] = fhi != 0xFFF00000u;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t (&iw)[8] = (g & 1) ? iwb : iwa;
+                    uint32_t (&iwn)[8] = (g & 1) ? iwa : iwb;
+                    fin[g] = kNoStep;
+                    uint32_t fhi = 0xFFF00000u;
+                    e6_load_quarter<C>(lds0, values, hot_bytes, iw, 1, svb);
+                    if (g < 3) load_iw(g + 1, iwn);
+                    relax5_step<0>(sva[0], acc, bpv, fin[g], fhi);
+                    relax5_step<1>(sva[1], acc, bpv, fin[g], fhi);
+                    relax5_step<2>(sva[2], acc, bpv, fin[g], fhi);
+                    relax5_step<3>(sva[3], acc, bpv, fin[g], fhi);
+                    e6_load_quarter<C>(lds0, values, hot_bytes, iw, 2, sva);
+                    relax5_step<4>(svb[0], acc, bpv, fin[g], fhi);
+                    relax5_step<5>(svb[1], acc, bpv, fin[g], fhi);
+                    relax5_step<6>(svb[2], acc, bpv, fin[g], fhi);
+                    relax5_step<7>(svb[3], acc, bpv, fin[g], fhi);
+                    e6_load_quarter<C>(lds0, values, hot_bytes, iw, 3, svb);
+                    relax5_step<8>(sva[0], acc, bpv, fin[g], fhi);
+                    relax5_step<9>(sva[1], acc, bpv, fin[g], fhi);
+                    relax5_step<10>(sva[2], acc, bpv, fin[g], fhi);
+                    relax5_step<11>(sva[3], acc, bpv, fin[g], fhi);
+                    if (g < 3) e6_load_quarter<C>(lds0, values, hot_bytes, iwn, 0, sva);
+                    relax5_step<12>(svb[0], acc, bpv, fin[g], fhi);
+                    relax5_step<13>(svb[1], acc, bpv, fin[g], fhi);
+                    relax5_step<14>(svb[2], acc, bpv, fin[g], fhi);
+                    relax5_step<15>(svb[3], acc, bpv, fin[g], fhi);
+                    reached[g] = fhi != 0xFFF00000u;
+                }
+            };
+            bool unresolved = false;
+            if (COLD) unresolved = live && (Q.pool == 0u || lds_load(&ctrl->pool_used[slot]) > Q.pool);
+            if (COLD && __builtin_expect(__builtin_amdgcn_ballot_w64(unresolved) != 0, 0)) relax_trip(std::true_type{});
+            else relax_trip(std::false_type{});
             if (!live) {  // a row without a sample went through the motions on an all-"no token" slot
                 acc = acc_in;
                 bpv = bpv_in;
@@ -872,6 +937,7 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
                 uint4* mine = reinterpret_cast<uint4*>(smem + slot_off + r * kE5RowStride + ((l - 1u) & 15u) * 32u);
                 mine[0] = make_uint4(0, 0, 0, 0);
                 mine[1] = make_uint4(0, 0, 0, 0);
+                if (COLD && lane == 0u) lds_store(&ctrl->pool_used[slot], 0u);
             }
             __builtin_amdgcn_wave_barrier();
             uint32_t pg[1] = {pgl}, maxd[1], wlane[1], c[1];
@@ -886,7 +952,17 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
             uint32_t l32 = l * 32u;
             asm volatile("" : "+v"(l32));
             WalkCtx<1> W{trie_b, s, l32, P.dropout, P.seed};
-            Walk5<DROPOUT, false, 1, 0>::run(W, bytes, maxd, pg, wlane, alive, rec, c);
+            Res5 R{};
+            if (COLD) {
+                R.cold = values;
+                R.tab = lds0;
+                R.shift = shift;
+                R.hot_max = shift + Q.n_hot;
+                R.used_off = lds0 + Q.ctrl_off + rw * (uint32_t)sizeof(E6Ctrl) + (uint32_t)offsetof(E6Ctrl, pool_used) + slot * 4u;
+                R.first = 1u + (rw * G + slot) * Q.pool;
+                R.cap = Q.pool;
+            }
+            Walk5<DROPOUT, false, COLD, 1, 0>::run(W, R, bytes, maxd, pg, wlane, alive, rec, c);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0u) lds_store(&ctrl->walk_done[slot], t + 1u);
         }
@@ -938,8 +1014,8 @@ hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, bool long_to
 
 // LDS of an encode6_kernel block: score table, root records, control words of the four rows, four rings of
 // kE6Slots match-index buffers
-uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
-    const uint32_t score_bytes = 8u * (n_hot + 1u);
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off) {
+    const uint32_t score_bytes = 8u * (1u + 4u * kE6Slots * pool + n_hot);
     const uint32_t ro = (score_bytes + 15u) & ~15u;
     const uint32_t co = ro + 2048u;
     const uint32_t go = (co + 4u * (uint32_t)sizeof(E6Ctrl) + 511u) & ~511u;
@@ -948,14 +1024,18 @@ uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t* root_off, uint32_t* ctrl_o
     if (ring_off) *ring_off = go;
     return go + 4u * kE6Slots * kE5GroupBytes;
 }
-uint32_t encode6_max_hot(uint32_t budget) {
-    const uint32_t fixed = encode6_lds_layout(0u, nullptr, nullptr, nullptr) + 512u;
+uint32_t encode6_pool_total(uint32_t pool) { return 4u * kE6Slots * pool; }
+uint32_t encode6_max_hot(uint32_t budget, uint32_t pool) {
+    const uint32_t fixed = encode6_lds_layout(0u, pool, nullptr, nullptr, nullptr) + 512u;
     return budget > fixed + 64u ? (budget - fixed) / 8u : 0u;
 }
 hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream) {
     q.ring_slots = kE6Slots;
-    const uint32_t lds = encode6_lds_layout(q.n_hot, &q.root_off, &q.ctrl_off, &q.ring_off);
-    if (lds > 160u * 1024u || q.n_hot > q.n_values) return hipErrorInvalidValue;
+    if (!cold) q.pool = 0u;
+    const uint32_t lds = encode6_lds_layout(q.n_hot, q.pool, &q.root_off, &q.ctrl_off, &q.ring_off);
+    if (lds > 160u * 1024u || q.n_hot > q.n_values || (!cold && q.n_hot != q.n_values) ||
+        (uint64_t)q.n_values + 4ull * kE6Slots * q.pool > 65535ull)
+        return hipErrorInvalidValue;
     auto fn = cold ? (p.dropout > 0.0 ? encode6_kernel<true, true> : encode6_kernel<false, true>)
                    : (p.dropout > 0.0 ? encode6_kernel<true, false> : encode6_kernel<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -44,6 +44,7 @@ struct Encode5Params {
     uint32_t claim_chunk;           // consecutive samples of the order a row claims per atomic (>= 1)
     uint32_t list_off, root_off, idx_off;  // LDS layout (set by the launcher)
     uint32_t ctrl_off, ring_off, ring_slots;  // encode6_kernel: control words, ring of match-index buffers
+    uint32_t pool;                            // encode6_kernel, COLD builds: pool entries per ring slot for values its walkers fetch (0: none)
 };
 
 struct CompactParams {
@@ -153,8 +154,9 @@ hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stre
 uint32_t encode5_lds_layout(uint32_t n_hot, bool long_tokens, int waves, int ppl, uint32_t* list_off, uint32_t* root_off, uint32_t* idx_off);
 uint32_t encode5_max_hot(bool long_tokens, int waves, int ppl, uint32_t budget);
 hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, bool long_tokens, int* out);
-uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
-uint32_t encode6_max_hot(uint32_t budget);
+uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
+uint32_t encode6_max_hot(uint32_t budget, uint32_t pool);
+uint32_t encode6_pool_total(uint32_t pool);  // pool entries of a block (index space they take)
 hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, bool long_tokens, int waves, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip

@@ -474,14 +474,32 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         // Its LDS copy of the value table is what two blocks per CU leave room for (~4 500 values).
         int e6_bpc = 2;
         if (const char* e = knob("TGX_E6_BPC")) e6_bpc = std::min(4, std::max(1, atoi(e)));
-        uint32_t n_hot6 = std::min(m->n_values, tgx::encode6_max_hot(160u * 1024u / (uint32_t)e6_bpc));
+        uint32_t n_hot6 = std::min(m->n_values, tgx::encode6_max_hot(160u * 1024u / (uint32_t)e6_bpc, 0u));
+        // More values than that: the walkers fetch the values beyond the LDS copy into `pool6` pool entries per ring
+        // slot (encode5.hip: Res5), and the relaxer reads from L2 only what a full pool left behind.
+        // 128 entries per slot (64 positions): 64 MiB / 256 MiB of the bench corpus take 2.70 / 6.06 ms with the
+        // 9 652-value vocabulary and 2.73 / 6.12 ms with 32 000 values (64 entries: 2.91 / 6.20 and 3.69 / 7.54;
+        // no pool, round 2: 4.88 / 9.82 and 5.04 / 10.11; every value in LDS: 2.64 / 5.45 — profiles/r03).
+        uint32_t pool6 = 0;
+        bool e6_usable = true;
+        if (n_hot6 < m->n_values) {
+            pool6 = 128;
+            if (const char* e = knob("TGX_E6_POOL")) pool6 = (uint32_t)std::min(192, std::max(0, atoi(e)));
+            if ((uint64_t)m->n_values + tgx::encode6_pool_total(pool6) > 65535ull) {
+                // indices are 16 bits: no room for pool entries, and a relaxer that reads the cold values itself is
+                // slower than encode5_kernel on everything but a lone long sample
+                pool6 = 0;
+                e6_usable = knob("TGX_E6_POOL") != nullptr || knob("TGX_LONG_THRESHOLD") != nullptr;
+            }
+            n_hot6 = std::min(m->n_values, tgx::encode6_max_hot(160u * 1024u / (uint32_t)e6_bpc, pool6));
+        }
         if (const char* e = knob("TGX_E5_HOT")) {
             const int v = atoi(e);
             if (v >= 0) n_hot6 = std::min(n_hot6, (uint32_t)v);
         }
         const bool cold6 = n_hot6 < m->n_values;
         uint64_t n_long = 0;
-        if (c->n_samples && !long_tokens) {  // (encode6_kernel walks 16 bytes)
+        if (c->n_samples && !long_tokens && e6_usable) {  // (encode6_kernel walks 16 bytes)
             const auto count_ge = [&](uint64_t thr) {  // h_sorted_len descends: the long samples are a prefix of the order
                 return (uint64_t)(std::partition_point(c->h_sorted_len.begin(), c->h_sorted_len.end(),
                                                        [thr](uint32_t len) { return len >= thr; }) - c->h_sorted_len.begin());
@@ -493,7 +511,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 const double N = (double)c->n_bytes;
                 auto cost = [&](uint64_t k) {  // the k longest samples to encode6_kernel
                     const double bytes_long = k ? (double)c->h_sorted_cum[k - 1] : 0.0;
-                    const double t6 = k ? std::max((double)c->h_sorted_len[0] * 0.0369e-6, bytes_long / 55e9) + 20e-6 : 0.0;
+                    const double t6 = k ? std::max((double)c->h_sorted_len[0] * (cold6 ? 0.042e-6 : 0.0369e-6), bytes_long / (cold6 ? 46e9 : 55e9)) + 20e-6 : 0.0;
                     const double rest_max = k < c->n_samples ? (double)c->h_sorted_len[k] : 0.0;
                     const double t5 = std::max(rest_max * 0.104e-6, (N - bytes_long) / 88e9);
                     return t6 + t5;
@@ -518,6 +536,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             time_begin(m, "encode6_kernel");
             tgx::Encode5Params q6 = q;
             q6.n_hot = n_hot6;
+            q6.pool = cold6 ? pool6 : 0u;
             HIP_TRY(tgx::launch_encode6(p6, q6, cold6, blocks6, m->stream));
             time_end(m);
             HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode5_kernel

@@ -12,6 +12,14 @@ for ml in 4096 1024 256; do python bench.py --max-sample-len $ml --no-cpu-baseli
 python bench.py --vocab 65536 --no-e2e > $O/bench_vocab_65536.json 2>/dev/null
 python bench.py --kind ascii --no-e2e > $O/bench_ascii.json 2>/dev/null
 python bench.py --distinct-scores --no-e2e > $O/bench_distinct_scores.json 2>/dev/null
+python bench.py --vocab 65536 --distinct-scores --no-e2e --no-cpu-baseline > $O/bench_vocab_65536_distinct_scores.json 2>/dev/null
+python bench.py --vocab-slice-mb 2 --no-e2e --no-cpu-baseline > $O/bench_vocab_2MiB_slice.json 2>/dev/null
+python bench.py --max-token-length 24 --distinct-scores --no-cpu-baseline --no-e2e > $O/bench_max_token_24_distinct_scores.json 2>/dev/null
+python tools/merged_vocab_bench.py > $O/merged_vocab_bench.json 2>/dev/null
+for sz in 10 64 256 512; do python bench.py --size-mb $sz --no-cpu-baseline --no-e2e | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print($sz, d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"; done > $O/bench_by_size_spec_vocabulary.txt 2>/dev/null
+for sz in 10 64 256 512; do python bench.py --size-mb $sz --distinct-scores --no-cpu-baseline --no-e2e | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print($sz, d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"; done > $O/bench_by_size_distinct_scores.txt 2>/dev/null
+python tools/generate_bench.py > $O/generate_bench.txt 2>&1
+python tools/python_api_rate.py > $O/python_api_rate.json 2>/dev/null
 python bench.py --size-mb 4096 --no-cpu-baseline --no-e2e --steps 3 --warmup 1 > $O/bench_4GiB.json 2>/dev/null
 python bench.py --max-token-length 24 --no-cpu-baseline --no-e2e > $O/bench_max_token_24.json 2>/dev/null
 python tests/measure/passes_bench.py 1024 32000 16 > $O/passes_1GiB.json 2>/dev/null
