@@ -293,6 +293,9 @@ uint32_t tgx_last_encode_waves_per_cu(const tgx_model *m);
 uint64_t tgx_last_encode_redo_samples(const tgx_model *m);
 /* samples of the last encode pass that had a block of their own (the long-sample kernel) */
 uint64_t tgx_last_encode_long_samples(const tgx_model *m);
+/* pieces the last tgx_estep pass cut its snippets into at positions no token match crosses (the lattice factorises
+ * there, so expected counts and log Z of the pieces add up to the snippets': csrc/cuts.hip); 0: snippets uncut. */
+uint64_t tgx_last_estep_pieces(const tgx_model *m);
 /* distinct score values of the vocabulary as the rows5 encode kernels rank them (0: the model has no 8-byte
  * records — tokens longer than 16 bytes, non-finite scores, more than 65 535 distinct values — or has not
  * encoded yet when it was created for E-step passes), and how many of them the last encode5_kernel launch

@@ -329,3 +329,74 @@ def test_count_pairs_top_is_the_head_of_the_full_table():
     e_flat, e_offs = tgx.pack([b"", b"a"])
     tk, tc, total = nat.count_pairs_top(tgx.NativeCorpus(e_flat, e_offs), 10)   # no pair at all
     assert tk.size == 0 and total == 0
+
+
+# ---- round 3: snippets cut where no token match crosses (csrc/cuts.hip) ---------------------------------------------
+
+@pytest.mark.parametrize("window", ["256", "2048"])
+def test_estep_on_pieces_equals_the_oracle(monkeypatch, window):
+    """The lattice factorises at a position no match crosses, so a pass over the pieces gives the expected counts
+    and log Z of the pass over whole snippets: long samples (one of 300 000 bytes -> four reference snippets), forced
+    piece mode with a small and the default window, with and without dropout, tokens up to 16 and up to 24 bytes.
+    (Tolerance as for whole snippets: it is the ORACLE's log-domain rounding that grows with its snippet length.)"""
+    monkeypatch.setenv("TGX_ESTEP_PIECES", "1")
+    monkeypatch.setenv("TGX_ESTEP_WINDOW", window)
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 8000, 16, seed_offset=61)
+    nat, ora = _pair(toks, scores)
+    n_samples = offs.size - 1
+    _check_estep(nat, ora, flat, offs)
+    assert nat.last_estep_pieces() > 2 * n_samples and "cut_windows_kernel" in nat.last_kernel_times()
+    _check_estep(nat, ora, flat, offs, dropout=0.3, seed=11)
+    assert nat.last_estep_pieces() > 2 * n_samples
+    offs2 = np.array([0, 300000, 300001, 1 << 20], dtype=np.uint64)
+    _check_estep(nat, ora, flat[: 1 << 20], offs2)
+    assert nat.last_estep_pieces() > 100
+    rng = np.random.default_rng(10)
+    toks24, scores24 = synth.random_vocab(rng, bytes(flat[: 64 << 10]), 2500, 24, tie_fraction=0.0)
+    nat24, ora24 = _pair(toks24, scores24)
+    _check_estep(nat24, ora24, flat[: 1 << 20], offs2)
+    assert nat24.last_estep_pieces() > 100
+    _check_estep(nat24, ora24, flat[: 1 << 20], offs2, dropout=0.2, seed=3)
+
+
+def test_estep_pieces_where_the_text_has_no_cut(monkeypatch):
+    """A run of one byte under the tokens a, aa, aaaa is crossed everywhere: no window finds a boundary, the snippets
+    stay whole (and a text with cuts only every ~1 000 bytes gets pieces of that size); results as without pieces."""
+    monkeypatch.setenv("TGX_ESTEP_PIECES", "1")
+    monkeypatch.setenv("TGX_ESTEP_WINDOW", "256")
+    toks = [b"a", b"aa", b"aaaa", b"b", b"ab"]
+    scores = [-1.0, -1.6, -2.5, -2.0, -2.2]
+    nat, ora = _pair(toks, scores)
+    texts = [b"a" * 5000, b"a" * 300 + b"b" + b"a" * 2000, (b"a" * 999 + b"b") * 8, b"ab" * 700]
+    flat, offs = tgx.pack(texts)
+    _check_estep(nat, ora, flat, offs)
+    # sample 0: none; sample 1: the cut before "b" is inside window 1 (a cut AFTER "b" does not exist: "ab" crosses it... and
+    # "b" + "a" has no token across) — only the totals are asserted: more pieces than samples, far fewer than windows
+    assert len(texts) <= nat.last_estep_pieces() < 40
+
+
+def test_estep_pieces_fall_back_to_whole_snippets_for_the_log_domain(monkeypatch):
+    """A byte that is no token leaves positions nothing reaches (lattice.rs:255): the linear-domain pass over the pieces
+    raises its flag and the log-domain kernels redo the pass on the uncut snippets — the reference's values."""
+    monkeypatch.setenv("TGX_ESTEP_PIECES", "1")
+    monkeypatch.setenv("TGX_ESTEP_WINDOW", "256")
+    toks = [b"a", b"b", b"ab", b"ba", b"aba", b"c", b"bcb"]
+    scores = [-1.0, -1.5, -1.7, -2.0, -2.2, -3.0, -0.5]
+    nat, ora = _pair(toks, scores)
+    texts = [b"abaabab" * 300, b"ab" * 1000 + b"\xff" + b"abc" * 400, b"cbcb" * 500]
+    flat, offs = tgx.pack(texts)
+    _check_estep(nat, ora, flat, offs)
+    assert any(k.startswith("estep4_") for k in nat.last_kernel_times())
+
+
+def test_estep_pieces_by_default_on_a_chain_bound_batch():
+    """By default a pass is cut into pieces when the estimate says its longest snippets bound it: a 16 MiB batch of
+    samples up to 64 KiB is, a batch of samples up to 2 KiB is not."""
+    flat, offs, toks, scores = corpus_and_vocab(16 << 20, "mixed", 8000, 16, seed_offset=62)
+    nat, ora = _pair(toks, scores)
+    _check_estep(nat, ora, flat, offs)
+    assert nat.last_estep_pieces() > offs.size - 1
+    f2, o2 = synth.make_corpus(4 << 20, "mixed", max_len=2048, seed_offset=63)
+    corpus = tgx.NativeCorpus(f2, o2)
+    nat.estep(corpus)
+    assert nat.last_estep_pieces() == 0

@@ -90,6 +90,7 @@ SYMBOLS = {
     "tgx_model_score_values": (_u32, [_vp]),
     "tgx_last_encode_hot_values": (_u32, [_vp]),
     "tgx_last_encode_long_samples": (_u64, [_vp]),
+    "tgx_last_estep_pieces": (_u64, [_vp]),
 }
 
 
@@ -546,6 +547,9 @@ class NativeModel:
 
     def last_encode_long_samples(self) -> int:
         return lib.tgx_last_encode_long_samples(self._h)
+
+    def last_estep_pieces(self) -> int:
+        return lib.tgx_last_estep_pieces(self._h)
 
 
 class FlatTrie:

@@ -128,6 +128,35 @@ struct Estep4Params {
     double dropout;
     uint64_t seed;
 };
+// cuts.hip: positions no token match crosses (the lattice factorises there): long snippets are cut into pieces
+struct CutParams {
+    const uint8_t* text;
+    const uint64_t* soffs;          // u64[K+1] snippets
+    const uint32_t* snip_sample;    // u32[K], u64[K]: dropout hash bookkeeping of the snippets
+    const uint64_t* snip_base;
+    const uint32_t* win_snip;       // u32[W] snippet of window w (windows in text order)
+    const uint32_t* win_k;          // u32[W] its number within the snippet; window 0 stands for the snippet's start
+    uint64_t n_windows;
+    uint32_t window;                // bytes per window
+    const void* trie;               // 16-byte records (check, base | terminal << 31, ...)
+    uint32_t root;
+    uint32_t lmx;                   // longest token, rounded up to 16 or 32
+    double dropout;
+    uint64_t seed;
+    uint64_t* bound;                // out u64[W]: the window's boundary (absolute byte offset) or ~0
+    uint32_t* flag;                 // out u32[W]: 1 iff bound[w] != ~0
+};
+hipError_t launch_cut_windows(const CutParams& p, hipStream_t stream);
+hipError_t launch_cut_scatter(const CutParams& p, const uint64_t* pos, uint64_t n_bytes, uint64_t* poffs, uint32_t* psample,
+                              uint64_t* pbase, uint32_t* psnip, hipStream_t stream);
+hipError_t launch_piece_len(const uint64_t* poffs, const uint64_t* n_pieces, uint32_t* len, uint32_t* idx, unsigned long long* longest,
+                            uint64_t cap, hipStream_t stream);
+hipError_t piece_sort_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t piece_sort(void* temp, size_t temp_bytes, const uint32_t* len_in, uint32_t* len_out, const uint32_t* idx_in, uint32_t* idx_out,
+                      uint64_t n, hipStream_t stream);
+hipError_t launch_piece_z_check(const double* zarr, const uint32_t* psnip, uint64_t n_pieces, double* zsnip, uint64_t n_snips,
+                                unsigned long long* err_snip, hipStream_t stream);
+
 hipError_t estep4_prepare();
 hipError_t launch_estep4_fwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
 hipError_t launch_estep4_bwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);

@@ -193,6 +193,7 @@ struct tgx_model {
     void* d_trie_w = nullptr;       // forward / reversed tables with w = exp(score) in place of the score
     void* d_trie_rev_w = nullptr;   //   (linear-domain E-step, estep4l.hip)
     uint64_t last_long_samples = 0;    // samples the last pass gave a block of their own (encode6_kernel)
+    uint64_t last_estep_pieces = 0;    // pieces the last E-step cut its snippets into (0: uncut)
     uint64_t last_redo_samples = 0;    // samples the last encode4l pass left to encode2_kernel
     int last_encode_waves_per_cu = 0;  // resident waves per CU of the last rows4 encode launch (self-check)
     bool estep_linear_ok = false;   // tables for the linear-domain E-step kernels exist
@@ -240,6 +241,11 @@ struct tgx_corpus {
         uint64_t *d_soffs = nullptr, *d_sbase = nullptr;
         uint32_t *d_order = nullptr, *d_ssample = nullptr;
         size_t obytes = 0, ordbytes = 0;
+        // windows of the snippets (cuts.hip: one boundary is sought per window): built with the work list
+        uint32_t window = 0;
+        uint64_t n_windows = 0;
+        uint32_t *d_win_snip = nullptr, *d_win_k = nullptr;
+        size_t winbytes = 0;
     } es;
     // the scratch above belongs to the corpus, so a pass holds this lock too (always after its model's):
     // two models may work on one resident corpus from two host threads (prune and merge do, src/prune.rs:48)
@@ -1257,6 +1263,8 @@ void tgx_corpus_free(tgx_corpus* c) {
     pool_free(c->device, c->es.d_sbase, c->es.obytes);
     pool_free(c->device, c->es.d_order, c->es.ordbytes);
     pool_free(c->device, c->es.d_ssample, c->es.ordbytes);
+    pool_free(c->device, c->es.d_win_snip, c->es.winbytes);
+    pool_free(c->device, c->es.d_win_k, c->es.winbytes);
     delete c;
 }
 
@@ -1907,8 +1915,13 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         pool_free(c->device, es.d_sbase, es.obytes);
         pool_free(c->device, es.d_order, es.ordbytes);
         pool_free(c->device, es.d_ssample, es.ordbytes);
+        pool_free(c->device, es.d_win_snip, es.winbytes);
+        pool_free(c->device, es.d_win_k, es.winbytes);
         es.d_soffs = es.d_sbase = nullptr;
         es.d_order = es.d_ssample = nullptr;
+        es.d_win_snip = es.d_win_k = nullptr;
+        es.window = 0;
+        es.n_windows = 0;
         es.snippet_len = 0;
         es.soffs.clear();
         es.ssample.clear();
@@ -1956,19 +1969,153 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     uint32_t* const d_order = es.d_order;
     uint32_t* const d_ssample = es.d_ssample;
     const size_t n_rev = m->flat_rev.table.size();
-    // replicas of the expected-count array (see estep4_bwd_kernel): up to 256, within 512 MiB
-    uint32_t n_rep = 256;
-    while (n_rep > 1 && (size_t)n_rep * n_rev * 8 > (512ull << 20)) n_rep >>= 1;
-    const size_t abytes = (size_t)(N + K + 128) * 8, ebytes = (size_t)(n_rep + 1) * n_rev * 8 + 256, zbytes = (size_t)K * 8 + 256;
-    double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr, *d_zarr = nullptr;
-    int32_t* d_aexp = nullptr;  // block exponents of alpha (linear-domain kernels)
-    const size_t xbytes = (size_t)((N >> 4) + K + 128) * 4;
     // TGX_ESTEP=log keeps the log-domain kernels (A/B timing, tests of both)
     const char* force_log = knob("TGX_ESTEP");
     const bool linear = m->estep_linear_ok && !(force_log && strcmp(force_log, "log") == 0);
+
+    // ---- pieces (cuts.hip): a pass bound by the serial chains of its longest snippets cuts them where no token match
+    // crosses — the lattice factorises there — and runs the linear-domain kernels on pieces of about `window` bytes.
+    // Estimates as below (1 position per lane: forward 52 GB/s and 14.5 ms per 64 KiB of chain, backward 21 GB/s and
+    // 29 ms); TGX_ESTEP_PIECES=0 / 1 forces, TGX_ESTEP_WINDOW sets the window.
+    struct Pieces {
+        uint64_t n = 0, longest = 0, cap = 0;
+        uint64_t *d_bound = nullptr, *d_pos = nullptr, *d_offs = nullptr, *d_base = nullptr;
+        uint32_t *d_flag = nullptr, *d_sample = nullptr, *d_snip = nullptr, *d_len = nullptr, *d_idx = nullptr, *d_len2 = nullptr, *d_order = nullptr;
+        void *d_scan = nullptr, *d_sort = nullptr;
+        double* d_zsnip = nullptr;
+        size_t scan_bytes = 0, sort_bytes = 0, zsnip_bytes = 0;
+    } pc;
+    auto free_pieces = [&]() {
+        pool_free(m->device, pc.d_bound, pc.cap * 8 + 256);
+        pool_free(m->device, pc.d_pos, (pc.cap + 1) * 8 + 256);
+        pool_free(m->device, pc.d_offs, (pc.cap + 1) * 8 + 256);
+        pool_free(m->device, pc.d_base, pc.cap * 8 + 256);
+        pool_free(m->device, pc.d_flag, (pc.cap + 1) * 4 + 256);
+        pool_free(m->device, pc.d_sample, pc.cap * 4 + 256);
+        pool_free(m->device, pc.d_snip, pc.cap * 4 + 256);
+        pool_free(m->device, pc.d_len, pc.cap * 4 + 256);
+        pool_free(m->device, pc.d_idx, pc.cap * 4 + 256);
+        pool_free(m->device, pc.d_len2, pc.cap * 4 + 256);
+        pool_free(m->device, pc.d_order, pc.cap * 4 + 256);
+        pool_free(m->device, pc.d_scan, pc.scan_bytes);
+        pool_free(m->device, pc.d_sort, pc.sort_bytes);
+        pool_free(m->device, pc.d_zsnip, pc.zsnip_bytes);
+        pc = Pieces{};
+    };
+    bool pieces = false;
+    if (linear && K && m->lm <= 32) {
+        uint32_t window = 2048;
+        if (const char* e = knob("TGX_ESTEP_WINDOW")) window = (uint32_t)std::min(1 << 20, std::max(256, atoi(e)));
+        const double longest0 = (double)(soffs[order[0] + 1] - soffs[order[0]]);
+        const double t_chain = longest0 / 65536.0 * (9.0 + 20.9) * 1e-3;     // the best chains of either kernel
+        const double t_thru = (double)N / 52e9 + (double)N / 21e9;
+        pieces = longest0 > 4.0 * window && t_chain > 1.15 * t_thru;
+        if (const char* e = knob("TGX_ESTEP_PIECES")) pieces = atoi(e) != 0 && longest0 > (double)window;
+        if (pieces && (es.window != window || !es.d_win_snip)) {
+            pool_free(c->device, es.d_win_snip, es.winbytes);
+            pool_free(c->device, es.d_win_k, es.winbytes);
+            es.d_win_snip = es.d_win_k = nullptr;
+            es.window = 0;
+            std::vector<uint32_t> ws, wk;
+            ws.reserve(K + N / window + 2);
+            wk.reserve(K + N / window + 2);
+            for (uint64_t k = 0; k < K; k++) {
+                const uint64_t len = soffs[k + 1] - soffs[k];
+                for (uint64_t j = 0; j * window < len; j++) {
+                    ws.push_back((uint32_t)k);
+                    wk.push_back((uint32_t)j);
+                }
+            }
+            es.n_windows = ws.size();
+            es.winbytes = es.n_windows * 4 + 256;
+            if (pool_alloc(c->device, es.winbytes, (void**)&es.d_win_snip) != hipSuccess ||
+                pool_alloc(c->device, es.winbytes, (void**)&es.d_win_k) != hipSuccess)
+                return fail(TGX_ERR_DEVICE, "out of device memory (E-step windows)");
+            if (hipMemcpyAsync(es.d_win_snip, ws.data(), es.n_windows * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+                hipMemcpyAsync(es.d_win_k, wk.data(), es.n_windows * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+                hipStreamSynchronize(m->stream) != hipSuccess)
+                return fail(TGX_ERR_DEVICE, "E-step window list upload failed");
+            es.window = window;
+        }
+    }
+    if (pieces) {
+        const uint64_t W = es.n_windows;
+        pc.cap = W;
+        pc.zsnip_bytes = (size_t)K * 8 + 256;
+        auto bad = [&](const char* what) {
+            (void)hipStreamSynchronize(m->stream);
+            free_pieces();
+            return fail(TGX_ERR_DEVICE, "E-step pieces: %s", what);
+        };
+        if (tgx::scan_temp_bytes(W, &pc.scan_bytes) != hipSuccess || tgx::piece_sort_temp_bytes(W, &pc.sort_bytes) != hipSuccess)
+            return bad("scratch sizes");
+        if (pool_alloc(m->device, W * 8 + 256, (void**)&pc.d_bound) != hipSuccess ||
+            pool_alloc(m->device, (W + 1) * 8 + 256, (void**)&pc.d_pos) != hipSuccess ||
+            pool_alloc(m->device, (W + 1) * 8 + 256, (void**)&pc.d_offs) != hipSuccess ||
+            pool_alloc(m->device, W * 8 + 256, (void**)&pc.d_base) != hipSuccess ||
+            pool_alloc(m->device, (W + 1) * 4 + 256, (void**)&pc.d_flag) != hipSuccess ||
+            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_sample) != hipSuccess ||
+            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_snip) != hipSuccess ||
+            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_len) != hipSuccess ||
+            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_idx) != hipSuccess ||
+            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_len2) != hipSuccess ||
+            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_order) != hipSuccess ||
+            (pc.scan_bytes && pool_alloc(m->device, pc.scan_bytes, &pc.d_scan) != hipSuccess) ||
+            (pc.sort_bytes && pool_alloc(m->device, pc.sort_bytes, &pc.d_sort) != hipSuccess) ||
+            pool_alloc(m->device, pc.zsnip_bytes, (void**)&pc.d_zsnip) != hipSuccess)
+            return bad("out of device memory");
+        tgx::CutParams q{};
+        q.text = c->d_text;
+        q.soffs = d_soffs;
+        q.snip_sample = d_ssample;
+        q.snip_base = d_sbase;
+        q.win_snip = es.d_win_snip;
+        q.win_k = es.d_win_k;
+        q.n_windows = W;
+        q.window = es.window;
+        q.trie = m->d_trie_w;
+        q.root = m->flat.table[0].base & ~tgx::kTerminalBit;
+        q.lmx = m->lm > 16 ? 32u : 16u;
+        q.dropout = dropout;
+        q.seed = seed;
+        q.bound = pc.d_bound;
+        q.flag = pc.d_flag;
+        unsigned long long* const d_longest = m->d_ctrl + 6;
+        time_begin(m, "cut_windows_kernel");
+        if (tgx::launch_cut_windows(q, m->stream) != hipSuccess) return bad("cut kernel launch failed");
+        time_end(m);
+        time_begin(m, "piece_list");
+        if (hipMemsetAsync(d_longest, 0, 8, m->stream) != hipSuccess || hipMemsetAsync(pc.d_zsnip, 0, pc.zsnip_bytes, m->stream) != hipSuccess ||
+            tgx::launch_scan(pc.d_flag, pc.d_pos, W, pc.d_scan, pc.scan_bytes, m->stream) != hipSuccess ||
+            tgx::launch_cut_scatter(q, pc.d_pos, N, pc.d_offs, pc.d_sample, pc.d_base, pc.d_snip, m->stream) != hipSuccess ||
+            tgx::launch_piece_len(pc.d_offs, pc.d_pos + W, pc.d_len, pc.d_idx, d_longest, W, m->stream) != hipSuccess ||
+            tgx::piece_sort(pc.d_sort, pc.sort_bytes, pc.d_len, pc.d_len2, pc.d_idx, pc.d_order, W, m->stream) != hipSuccess)
+            return bad("piece list kernels failed");
+        time_end(m);
+        unsigned long long h_n = 0, h_longest = 0;
+        if (hipMemcpyAsync(&h_n, pc.d_pos + W, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipMemcpyAsync(&h_longest, d_longest, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess)
+            return bad("piece list read-back failed");
+        if (h_n < K || h_n > W) return bad("inconsistent piece count");
+        pc.n = h_n;
+        pc.longest = h_longest;
+        m->last_estep_pieces = pc.n;
+    } else {
+        m->last_estep_pieces = 0;
+    }
+    const uint64_t Kmax = pieces ? std::max<uint64_t>(K, pc.n) : K;
+    // replicas of the expected-count array (see estep4_bwd_kernel): up to 256, within 512 MiB
+    uint32_t n_rep = 256;
+    while (n_rep > 1 && (size_t)n_rep * n_rev * 8 > (512ull << 20)) n_rep >>= 1;
+    const size_t abytes = (size_t)(N + Kmax + 128) * 8, ebytes = (size_t)(n_rep + 1) * n_rev * 8 + 256, zbytes = (size_t)Kmax * 8 + 256;
+    double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr, *d_zarr = nullptr;
+    int32_t* d_aexp = nullptr;  // block exponents of alpha (linear-domain kernels)
+    const size_t xbytes = (size_t)((N >> 4) + Kmax + 128) * 4;
     auto cleanup = [&](tgx_status s2) {
         // kernels already queued may still write these buffers: no other handle may take them from the pool yet
         if (s2 != TGX_OK) (void)hipStreamSynchronize(m->stream);
+        free_pieces();
         pool_free(m->device, d_alpha, abytes);
         pool_free(m->device, d_aexp, xbytes);
         pool_free(m->device, d_exp, ebytes);
@@ -2023,7 +2170,7 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     // 21 / 16 / 11 GB/s): tools/eppl_sweep.py on 1 x MI355X.  TGX_EPPL overrides both.
     int eppl_fwd = 1, eppl_bwd = 1;
     {
-        const double longest = K ? (double)(soffs[order[0] + 1] - soffs[order[0]]) / 65536.0 : 0.0;
+        const double longest = pieces ? (double)pc.longest / 65536.0 : (K ? (double)(soffs[order[0] + 1] - soffs[order[0]]) / 65536.0 : 0.0);
         const double f_gbps[3] = {52.0, 48.0, 33.0}, f_chain[3] = {14.5, 11.0, 9.0};
         // (the backward kernel with 2 positions per lane runs 8 groups of 16 positions per block and sums 8192
         // slots in LDS: tools/bwd_groups_sweep.py)
@@ -2044,6 +2191,13 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     for (;;) {
         p.trie_fwd = use_linear ? m->d_trie_w : m->d_trie;
         p.trie_rev = use_linear ? m->d_trie_rev_w : m->d_trie_rev;
+        const bool on_pieces = pieces && use_linear;  // (the log-domain kernels redo a pass on the uncut snippets: cuts.hip)
+        p.soffs = on_pieces ? pc.d_offs : d_soffs;
+        p.order = on_pieces ? pc.d_order : d_order;
+        p.n_snips = on_pieces ? pc.n : K;
+        p.snip_sample = on_pieces ? pc.d_sample : d_ssample;
+        p.snip_base = on_pieces ? pc.d_base : d_sbase;
+        p.err_snip = on_pieces ? m->d_ctrl + 7 : m->d_ctrl + 1;  // pieces: z is checked per snippet (launch_piece_z_check)
         if (hipMemsetAsync(m->d_ctrl + 3, 0x00, 24, m->stream) != hipSuccess ||
             hipMemsetAsync(d_z, 0, 256, m->stream) != hipSuccess ||
             hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
@@ -2072,6 +2226,8 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
                         : tgx::launch_estep4_bwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "estep4 backward launch failed"));
         time_end(m);
+        if (on_pieces && tgx::launch_piece_z_check(d_zarr, pc.d_snip, pc.n, pc.d_zsnip, K, m->d_ctrl + 1, m->stream) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "E-step z check launch failed"));
         break;
     }
     double* d_sum = d_exp + (size_t)n_rep * n_rev;  // replica sums
@@ -2235,6 +2391,7 @@ uint32_t tgx_last_encode_waves_per_cu(const tgx_model* m) { return m ? (uint32_t
 uint64_t tgx_last_algorithmic_bytes(const tgx_model* m) { return m ? m->last_alg_bytes : 0; }
 uint64_t tgx_last_encode_redo_samples(const tgx_model* m) { return m ? m->last_redo_samples : 0; }
 uint64_t tgx_last_encode_long_samples(const tgx_model* m) { return m ? m->last_long_samples : 0; }
+uint64_t tgx_last_estep_pieces(const tgx_model* m) { return m ? m->last_estep_pieces : 0; }
 uint32_t tgx_model_score_values(const tgx_model* m) { return m && m->have_trie8 ? m->n_values : 0u; }
 uint32_t tgx_last_encode_hot_values(const tgx_model* m) { return m ? m->last_n_hot : 0u; }
 
