@@ -2009,7 +2009,9 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         const double longest0 = (double)(soffs[order[0] + 1] - soffs[order[0]]);
         const double t_chain = longest0 / 65536.0 * (9.0 + 20.9) * 1e-3;     // the best chains of either kernel
         const double t_thru = (double)N / 52e9 + (double)N / 21e9;
-        pieces = longest0 > 4.0 * window && t_chain > 1.15 * t_thru;
+        // (measured, 32 000 entries, samples <= 64 KiB: 64 MiB 31.3 -> 4.1 ms, 256 MiB 33.0 -> 14.4, 512 MiB 44.8 -> 28.3,
+        // 1 GiB 57.1 -> 57.2: the longest chains delay a pass well before they bound it — profiles/r03)
+        pieces = longest0 > 4.0 * window && t_chain > 0.5 * t_thru;
         if (const char* e = knob("TGX_ESTEP_PIECES")) pieces = atoi(e) != 0 && longest0 > (double)window;
         if (pieces && (es.window != window || !es.d_win_snip)) {
             pool_free(c->device, es.d_win_snip, es.winbytes);
