@@ -702,17 +702,13 @@ hipError_t launch_estep4l_fwd(const Estep4Params& p, int ppl, bool long_tokens, 
     return hipGetLastError();
 }
 // backward: ONE block per CU: 16 / 8 / 4 waves x 4 KiB * ppl of match buffers (slots), the rest of the 160 KiB hot entries
-hipError_t launch_estep4l_bwd(const Estep4Params& p0, int ppl, bool long_tokens, uint32_t num_cus, hipStream_t stream) {
+hipError_t launch_estep4l_bwd(const Estep4Params& p0, int ppl, bool long_tokens, uint32_t num_cus, uint32_t groups_wanted, hipStream_t stream) {
     if (long_tokens) ppl = 1;
     // groups of 16 positions per block: 16 (x 4 KiB of match buffer) leave 96 KiB = 6 143 hot entries of 16
     // bytes; fewer groups, more slots summed in LDS instead of by memory-side atomics but fewer waves to hide
     // the gathers: 44.3 / 40.9 / 39.5 ms per GiB with 12 / 14 / 16 groups, 51.0 ms with the 12 groups and
-    // 2 048 hot slots that 12-byte match entries allowed (profiles/r02; TGX_BWD_GROUPS overrides)
-    uint32_t groups = 16;
-    if (const char* e = getenv("TGX_BWD_GROUPS")) {
-        const int v = atoi(e);
-        if (v >= 4 && v <= 16) groups = (uint32_t)v;
-    }
+    // 2 048 hot slots that 12-byte match entries allowed (profiles/r02; groups_wanted: TGX_BWD_GROUPS, read by the caller)
+    const uint32_t groups = (groups_wanted >= 4u && groups_wanted <= 16u) ? groups_wanted : 16u;
     Estep4Params p = p0;
     const uint32_t waves = std::max(1u, groups / (uint32_t)ppl);
     const uint32_t wave_bytes = (uint32_t)ppl * kE4LEntries * 4u + (long_tokens ? kE4LOvfBytes : 0u);

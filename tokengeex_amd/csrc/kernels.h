@@ -162,7 +162,7 @@ hipError_t launch_estep4_fwd(const Estep4Params& p, uint32_t num_cus, hipStream_
 hipError_t launch_estep4_bwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
 hipError_t estep4l_prepare();
 hipError_t launch_estep4l_fwd(const Estep4Params& p, int ppl, bool long_tokens, uint32_t num_cus, hipStream_t stream);
-hipError_t launch_estep4l_bwd(const Estep4Params& p, int ppl, bool long_tokens, uint32_t num_cus, hipStream_t stream);
+hipError_t launch_estep4l_bwd(const Estep4Params& p, int ppl, bool long_tokens, uint32_t num_cus, uint32_t groups_wanted, hipStream_t stream);
 hipError_t launch_estep4_reduce(const double* rep, double* out, uint32_t n_slots, uint32_t n_replicas,
                                 hipStream_t stream);
 

@@ -2224,7 +2224,9 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             }
         }
         time_begin(m, use_linear ? "estep4l_bwd_kernel" : "estep4_bwd_kernel");
-        if ((use_linear ? tgx::launch_estep4l_bwd(p, eppl_bwd, long_tokens, (uint32_t)m->num_cus, m->stream)
+        uint32_t bwd_groups = 16;  // groups of 16 positions per block of the backward kernel (estep4l.hip)
+        if (const char* e = knob("TGX_BWD_GROUPS")) bwd_groups = (uint32_t)std::max(0, atoi(e));
+        if ((use_linear ? tgx::launch_estep4l_bwd(p, eppl_bwd, long_tokens, (uint32_t)m->num_cus, bwd_groups, m->stream)
                         : tgx::launch_estep4_bwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "estep4 backward launch failed"));
         time_end(m);

@@ -1,6 +1,7 @@
 """E-step backward kernel: groups of 16 positions per block (TGX_BWD_GROUPS) against hot slots in LDS.
 Fewer groups = fewer waves, but more expected counts summed in LDS instead of memory-side f64 atomics."""
 import os, sys
+os.environ["TGX_KNOBS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import tokengeex_amd as tgx
