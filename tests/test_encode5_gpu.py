@@ -32,7 +32,7 @@ def test_values_outside_the_lds_copy_are_read_by_the_relaxing_lane(monkeypatch, 
     assert "encode5_kernel" in kt and "encode4_kernel" not in kt and nat.last_encode_redo_samples() == 0
     assert nat.score_values() == 8000 and nat.last_encode_hot_values() == int(hot)
     assert_same_encoding(nat, ora, flat, offs, dropout=0.25, seed=3)
-    for ppl in ("1", "2"):
+    for ppl in ("1", "2", "3"):
         monkeypatch.setenv("TGX_PPL", ppl)
         assert_same_encoding(nat, ora, flat, offs)
 
@@ -51,7 +51,7 @@ def test_every_match_cold_and_sixteen_matches_per_position(monkeypatch):
     assert_same_encoding(nat, ora, f, o)
     assert "encode5_kernel" in nat.last_kernel_times() and nat.last_encode_hot_values() == 0
     assert_same_encoding(nat, ora, f, o, dropout=0.3, seed=5)
-    for ppl in ("1", "2"):
+    for ppl in ("1", "2", "3"):
         monkeypatch.setenv("TGX_PPL", ppl)
         assert_same_encoding(nat, ora, f, o)
 

@@ -312,7 +312,7 @@ __device__ __forceinline__ void e5_long_tail(__amdgpu_buffer_rsrc_t trie, const 
     }
 
 template <bool DROPOUT, bool COLD, int PPL, bool LONG>
-__global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : 1))) void encode5_kernel(EncodeParams P, Encode5Params Q) {
+__global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : (PPL == 3 ? 4 : 1)))) void encode5_kernel(EncodeParams P, Encode5Params Q) {
     static_assert(!LONG || PPL == 4, "the long-token build runs four positions per lane");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr uint32_t LM = LONG ? 32 : 16;
@@ -978,10 +978,12 @@ static encode5_fn pick_encode5(bool dropout, bool cold, int ppl, bool long_token
     if (cold) {
         if (ppl == 1) return dropout ? encode5_kernel<true, true, 1, false> : encode5_kernel<false, true, 1, false>;
         if (ppl == 2) return dropout ? encode5_kernel<true, true, 2, false> : encode5_kernel<false, true, 2, false>;
+        if (ppl == 3) return dropout ? encode5_kernel<true, true, 3, false> : encode5_kernel<false, true, 3, false>;
         return dropout ? encode5_kernel<true, true, 4, false> : encode5_kernel<false, true, 4, false>;
     }
     if (ppl == 1) return dropout ? encode5_kernel<true, false, 1, false> : encode5_kernel<false, false, 1, false>;
     if (ppl == 2) return dropout ? encode5_kernel<true, false, 2, false> : encode5_kernel<false, false, 2, false>;
+    if (ppl == 3) return dropout ? encode5_kernel<true, false, 3, false> : encode5_kernel<false, false, 3, false>;
     return dropout ? encode5_kernel<true, false, 4, false> : encode5_kernel<false, false, 4, false>;
 }
 

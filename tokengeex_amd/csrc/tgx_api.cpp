@@ -398,27 +398,41 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         //   * the same with 15 / 14 / 13 waves, every value in LDS: up to ~4 700 / 5 700 / 6 800 values, 11.4 - 12.3 ms;
         //   * two positions per lane, every value in LDS: up to ~11 900 values — the generate-style vocabularies
         //     of SURVEY.md 8(d), 9 652 values at 32 000 entries, 10 569 at 65 536 —, 12.7 ms;
-        //   * four positions per lane with the ~3 700 hottest values in LDS and the others read from L2 by the
-        //     relaxing lanes (COLD builds; every token its own score: after an M-step or merge), 14.2 - 14.6 ms.
+        //   * three positions per lane x 13 waves, every value in LDS: up to ~10 100 values, 12.5 ms;
+        //   * three positions per lane with the ~7 800 hottest values in LDS and the others read from L2 by the
+        //     relaxing lanes (COLD builds; every token its own score: after an M-step or merge), 14.0 ms.
         // Fewer waves when the batch has fewer samples than the chip has rows, so that they spread over the CUs.
         // Tokens of 17..32 bytes: the LONG build (four positions per lane, a list of long matches per wave).
-        int ppl = 4, bpc = 1, hot_waves = 16;  // hot_waves: the most waves beside which every value fits (four positions per lane)
+        int ppl = 4, bpc = 1, hot_waves = 16;  // hot_waves: the most waves beside which every value fits
         {
             int ps4 = 0;
             HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, 4, long_tokens, &ps4));
             hot_waves = std::min(16, ps4 * 4);
-            const int least = long_tokens ? 12 : 13;  // (the long-token build has no two-positions-per-lane variant to fall to)
+            const int least = long_tokens ? 12 : 13;  // (the long-token build has four positions per lane only)
             while (hot_waves >= least && m->n_values > tgx::encode5_max_hot(long_tokens, hot_waves, 4, 160u * 1024u)) hot_waves--;
             if (hot_waves < least) {
                 hot_waves = 0;  // not with four positions per lane
-                if (!long_tokens && m->n_values <= tgx::encode5_max_hot(false, 16, 2, 160u * 1024u)) ppl = 2;
+                if (!long_tokens) {
+                    // three positions per lane x 13 waves with every value in LDS (up to ~10 100: the 32 000-entry spec
+                    // vocabulary, 12.5 ms against 12.8 with two positions per lane); two x 16 (up to ~11 900: the
+                    // 65 536-entry one, 13.0 ms); else three x 16 with the ~7 800 hottest in LDS (every token its own
+                    // score: 14.0 ms against 14.4 with four positions per lane and 3 712) — profiles/r03/n_e5_ppl3_sweep.txt
+                    if (m->n_values <= tgx::encode5_max_hot(false, 13, 3, 160u * 1024u)) {
+                        ppl = 3;
+                        hot_waves = 13;
+                    } else if (m->n_values <= tgx::encode5_max_hot(false, 16, 2, 160u * 1024u)) {
+                        ppl = 2;
+                    } else {
+                        ppl = 3;
+                    }
+                }
             }
         }
         if (const char* e = long_tokens ? nullptr : knob("TGX_PPL")) {
             const int v = atoi(e);
-            if (v == 1 || v == 2 || v == 4) {
+            if (v >= 1 && v <= 4) {
                 ppl = v;
-                bpc = ppl == 4 ? 1 : 2;
+                bpc = ppl >= 3 ? 1 : 2;
             }
         }
         if (const char* e = knob("TGX_BPC")) {
@@ -430,7 +444,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         int per_simd = 0;
         HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, ppl, long_tokens, &per_simd));
         int waves = std::min(16, (per_simd / bpc) * 4);
-        if (ppl == 4 && bpc == 1 && hot_waves > 0) waves = std::min(waves, hot_waves);
+        if ((ppl == 4 || ppl == 3) && bpc == 1 && hot_waves > 0) waves = std::min(waves, hot_waves);
         if (m->n_values > tgx::encode5_max_hot(long_tokens, waves, ppl, budget)) {
             cold = true;
             HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, true, ppl, long_tokens, &per_simd));
