@@ -403,87 +403,6 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         //     relaxing lanes (COLD builds; every token its own score: after an M-step or merge), 14.0 ms.
         // Fewer waves when the batch has fewer samples than the chip has rows, so that they spread over the CUs.
         // Tokens of 17..32 bytes: the LONG build (four positions per lane, a list of long matches per wave).
-        int ppl = 4, bpc = 1, hot_waves = 16;  // hot_waves: the most waves beside which every value fits
-        {
-            int ps4 = 0;
-            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, 4, long_tokens, &ps4));
-            hot_waves = std::min(16, ps4 * 4);
-            const int least = long_tokens ? 12 : 13;  // (the long-token build has four positions per lane only)
-            while (hot_waves >= least && m->n_values > tgx::encode5_max_hot(long_tokens, hot_waves, 4, 160u * 1024u)) hot_waves--;
-            if (hot_waves < least) {
-                hot_waves = 0;  // not with four positions per lane
-                if (!long_tokens) {
-                    // three positions per lane x 13 waves with every value in LDS (up to ~10 100: the 32 000-entry spec
-                    // vocabulary, 12.5 ms against 12.8 with two positions per lane); two x 16 (up to ~11 900: the
-                    // 65 536-entry one, 13.0 ms); else three x 16 with the ~7 800 hottest in LDS (every token its own
-                    // score: 14.0 ms against 14.4 with four positions per lane and 3 712) — profiles/r03/n_e5_ppl3_sweep.txt
-                    if (m->n_values <= tgx::encode5_max_hot(false, 13, 3, 160u * 1024u)) {
-                        ppl = 3;
-                        hot_waves = 13;
-                    } else if (m->n_values <= tgx::encode5_max_hot(false, 16, 2, 160u * 1024u)) {
-                        ppl = 2;
-                    } else {
-                        ppl = 3;
-                    }
-                }
-            }
-        }
-        if (const char* e = long_tokens ? nullptr : knob("TGX_PPL")) {
-            const int v = atoi(e);
-            if (v >= 1 && v <= 4) {
-                ppl = v;
-                bpc = ppl >= 3 ? 1 : 2;
-            }
-        }
-        if (const char* e = knob("TGX_BPC")) {
-            const int v = atoi(e);
-            if (v >= 1 && v <= 8) bpc = v;
-        }
-        const uint32_t budget = 160u * 1024u / (uint32_t)bpc;
-        bool cold = false;
-        int per_simd = 0;
-        HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, ppl, long_tokens, &per_simd));
-        int waves = std::min(16, (per_simd / bpc) * 4);
-        if ((ppl == 4 || ppl == 3) && bpc == 1 && hot_waves > 0) waves = std::min(waves, hot_waves);
-        if (m->n_values > tgx::encode5_max_hot(long_tokens, waves, ppl, budget)) {
-            cold = true;
-            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, true, ppl, long_tokens, &per_simd));
-            waves = std::min(16, (per_simd / bpc) * 4);
-        }
-        {
-            const uint64_t rows_wanted = (c->n_samples + (uint64_t)m->num_cus * bpc - 1) / ((uint64_t)m->num_cus * bpc);
-            waves = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)waves, (rows_wanted + 3) / 4));
-        }
-        if (const char* e = knob("TGX_WAVES")) {
-            const int v = atoi(e);
-            if (v >= 1 && v <= 16) waves = v;
-        }
-        while (waves > 1 && tgx::encode5_max_hot(long_tokens, waves, ppl, budget) < 16u) waves--;
-        uint32_t n_hot = std::min(m->n_values, tgx::encode5_max_hot(long_tokens, waves, ppl, budget));
-        if (const char* e = knob("TGX_E5_HOT")) {  // tests of the COLD builds (a small LDS copy), table-size sweeps
-            const int v = atoi(e);
-            if (v >= 0) n_hot = std::min(n_hot, (uint32_t)v);
-        }
-        cold = n_hot < m->n_values;
-        m->last_n_hot = n_hot;
-        // whole blocks only: a block's waves are dealt round-robin to the SIMDs, ceil(waves / 4) on the fullest
-        m->last_encode_waves_per_cu = std::min(bpc, per_simd / ((waves + 3) / 4)) * waves;
-        const uint64_t rows_per_block = 4 * (uint64_t)waves;
-        const uint32_t blocks5 = (uint32_t)std::max<uint64_t>(
-            1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
-        tgx::Encode5Params q{};
-        q.trie8 = m->d_trie8;
-        q.trie_bytes = (uint32_t)(m->flat.table.size() * sizeof(tgx::Trie8Rec));
-        q.values = m->d_values;
-        q.root_base = m->root_base8;
-        q.n_values = m->n_values;
-        q.n_hot = n_hot;
-        {   // rows claim several consecutive samples of the order per atomic when samples are short: one global
-            // atomic round trip (~1-2 us) per sample is what a corpus of 130-byte samples otherwise waits for
-            const uint64_t avg = c->n_samples ? c->n_bytes / c->n_samples : 0;
-            q.claim_chunk = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, 4096 / std::max<uint64_t>(1, avg)));
-            if (const char* e = knob("TGX_CLAIM_CHUNK")) q.claim_chunk = (uint32_t)std::min(64, std::max(1, atoi(e)));
-        }
         m->last_redo_samples = 0;
         // Long samples first, four to a block (encode6_kernel: three walker waves per sample ahead of one row of the
         // block's relaxing wave), when that shortens the pass.  encode5_kernel takes ~0.104 us per byte of a
@@ -546,6 +465,107 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                     }
                 }
             }
+        }
+        // what is left for encode5_kernel: the samples from n_long on in the longest-first order
+        const uint64_t rest_n = c->n_samples - n_long;
+        const uint64_t rest_bytes = c->n_bytes - (n_long ? c->h_sorted_cum[n_long - 1] : 0);
+        const uint64_t rest_max = rest_n ? c->h_sorted_len[n_long] : 0;
+        int ppl = 4, bpc = 1, hot_waves = 16;  // hot_waves: the most waves beside which every value fits
+        {
+            int ps4 = 0;
+            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, 4, long_tokens, &ps4));
+            hot_waves = std::min(16, ps4 * 4);
+            const int least = long_tokens ? 12 : 13;  // (the long-token build has four positions per lane only)
+            while (hot_waves >= least && m->n_values > tgx::encode5_max_hot(long_tokens, hot_waves, 4, 160u * 1024u)) hot_waves--;
+            if (hot_waves < least) {
+                hot_waves = 0;  // not with four positions per lane
+                if (!long_tokens) {
+                    // three positions per lane x 13 waves with every value in LDS (up to ~10 100: the 32 000-entry spec
+                    // vocabulary, 12.5 ms against 12.8 with two positions per lane); two x 16 (up to ~11 900: the
+                    // 65 536-entry one, 13.0 ms); else three x 16 with the ~7 800 hottest in LDS (every token its own
+                    // score: 14.0 ms against 14.4 with four positions per lane and 3 712) — profiles/r03/n_e5_ppl3_sweep.txt
+                    if (m->n_values <= tgx::encode5_max_hot(false, 13, 3, 160u * 1024u)) {
+                        ppl = 3;
+                        hot_waves = 13;
+                    } else if (m->n_values <= tgx::encode5_max_hot(false, 16, 2, 160u * 1024u)) {
+                        ppl = 2;
+                    } else {
+                        ppl = 3;
+                    }
+                }
+            }
+        }
+        // A batch whose longest sample is more than a row's share of it is not bound by throughput but by the rows that
+        // drew the long samples: with rows = bytes / longest sample every row's share is one such sample, fewer waves run
+        // each faster, and their LDS takes every value with four positions per lane (the longest trips).  512 MiB of the
+        // bench corpus: 8 waves, 9.7 ms against 10.5 (three positions x 13 waves); with distinct scores 11.3 against 12.5
+        // (profiles/r03/o_split_and_geometry_by_size.txt).  From 11 waves on the throughput geometries above are faster.
+        int balance_waves = 0;
+        if (rest_max > 0) {
+            const uint64_t rows_bal = (rest_bytes + rest_max - 1) / rest_max;
+            const uint64_t wb = (rows_bal + 4ull * (uint64_t)m->num_cus - 1) / (4ull * (uint64_t)m->num_cus);
+            if (wb <= 10) {
+                balance_waves = (int)std::max<uint64_t>(4, wb);
+                ppl = 4;
+                hot_waves = 0;
+            }
+        }
+        if (const char* e = long_tokens ? nullptr : knob("TGX_PPL")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 4) {
+                ppl = v;
+                bpc = ppl >= 3 ? 1 : 2;
+            }
+        }
+        if (const char* e = knob("TGX_BPC")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8) bpc = v;
+        }
+        const uint32_t budget = 160u * 1024u / (uint32_t)bpc;
+        bool cold = false;
+        int per_simd = 0;
+        HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, false, ppl, long_tokens, &per_simd));
+        int waves = std::min(16, (per_simd / bpc) * 4);
+        if ((ppl == 4 || ppl == 3) && bpc == 1 && hot_waves > 0) waves = std::min(waves, hot_waves);
+        if (m->n_values > tgx::encode5_max_hot(long_tokens, waves, ppl, budget)) {
+            cold = true;
+            HIP_TRY(tgx::encode5_waves_per_simd(dropout > 0.0, true, ppl, long_tokens, &per_simd));
+            waves = std::min(16, (per_simd / bpc) * 4);
+        }
+        if (balance_waves > 0 && ppl == 4 && bpc == 1) waves = std::min(waves, balance_waves);
+        {
+            const uint64_t rows_wanted = (c->n_samples + (uint64_t)m->num_cus * bpc - 1) / ((uint64_t)m->num_cus * bpc);
+            waves = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)waves, (rows_wanted + 3) / 4));
+        }
+        if (const char* e = knob("TGX_WAVES")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 16) waves = v;
+        }
+        while (waves > 1 && tgx::encode5_max_hot(long_tokens, waves, ppl, budget) < 16u) waves--;
+        uint32_t n_hot = std::min(m->n_values, tgx::encode5_max_hot(long_tokens, waves, ppl, budget));
+        if (const char* e = knob("TGX_E5_HOT")) {  // tests of the COLD builds (a small LDS copy), table-size sweeps
+            const int v = atoi(e);
+            if (v >= 0) n_hot = std::min(n_hot, (uint32_t)v);
+        }
+        cold = n_hot < m->n_values;
+        m->last_n_hot = n_hot;
+        // whole blocks only: a block's waves are dealt round-robin to the SIMDs, ceil(waves / 4) on the fullest
+        m->last_encode_waves_per_cu = std::min(bpc, per_simd / ((waves + 3) / 4)) * waves;
+        const uint64_t rows_per_block = 4 * (uint64_t)waves;
+        const uint32_t blocks5 = (uint32_t)std::max<uint64_t>(
+            1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
+        tgx::Encode5Params q{};
+        q.trie8 = m->d_trie8;
+        q.trie_bytes = (uint32_t)(m->flat.table.size() * sizeof(tgx::Trie8Rec));
+        q.values = m->d_values;
+        q.root_base = m->root_base8;
+        q.n_values = m->n_values;
+        q.n_hot = n_hot;
+        {   // rows claim several consecutive samples of the order per atomic when samples are short: one global
+            // atomic round trip (~1-2 us) per sample is what a corpus of 130-byte samples otherwise waits for
+            const uint64_t avg = c->n_samples ? c->n_bytes / c->n_samples : 0;
+            q.claim_chunk = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, 4096 / std::max<uint64_t>(1, avg)));
+            if (const char* e = knob("TGX_CLAIM_CHUNK")) q.claim_chunk = (uint32_t)std::min(64, std::max(1, atoi(e)));
         }
         m->last_long_samples = n_long;
         if (n_long) {
