@@ -296,6 +296,9 @@ uint64_t tgx_last_encode_long_samples(const tgx_model *m);
 /* pieces the last tgx_estep pass cut its snippets into at positions no token match crosses (the lattice factorises
  * there, so expected counts and log Z of the pieces add up to the snippets': csrc/cuts.hip); 0: snippets uncut. */
 uint64_t tgx_last_estep_pieces(const tgx_model *m);
+/* CUs the long-sample kernel had to itself while encode5_kernel ran on the others in the last encode pass
+ * (batches of a few hundred MB whose longest samples bound either kernel alone); 0: the kernels ran one after the other. */
+uint32_t tgx_last_encode_corun_cus(const tgx_model *m);
 /* distinct score values of the vocabulary as the rows5 encode kernels rank them (0: the model has no 8-byte
  * records — tokens longer than 16 bytes, non-finite scores, more than 65 535 distinct values — or has not
  * encoded yet when it was created for E-step passes), and how many of them the last encode5_kernel launch

@@ -200,3 +200,24 @@ def test_long_sample_threshold_default():
     res = nat.encode_batch_flat(f2, o2)
     res.free()
     assert nat.last_encode_long_samples() == 0 and "encode6_kernel" not in nat.last_kernel_times()
+
+
+@pytest.mark.parametrize("cus", ["32", "96", "192"])
+def test_long_and_short_samples_at_once(monkeypatch, cus):
+    """Co-run (round 3): the long-sample kernel on CUs of its own (second stream, a work queue of its own) while
+    encode5_kernel takes the rest of the batch on the others — forced here with a low threshold; every value in LDS and
+    distinct scores (cold values through the walkers' pools), dropout; bit-exact against the oracle."""
+    monkeypatch.setenv("TGX_LONG_THRESHOLD", "3000")
+    monkeypatch.setenv("TGX_CORUN", cus)
+    rng = np.random.default_rng(23)
+    flat, offs, toks, scores = corpus_and_vocab(4 << 20, "mixed", 8000, 16, seed_offset=71, max_len=40000)
+    for sc in (scores, _distinct_scores(scores, rng)):
+        nat, ora = tgx.NativeModel(toks, sc), orc.OracleModel(toks, sc)
+        assert_same_encoding(nat, ora, flat, offs)
+        kt = nat.last_kernel_times()
+        assert nat.last_encode_corun_cus() == int(cus) and "encode6_kernel" in kt and "encode5_kernel" in kt
+        assert 0 < nat.last_encode_long_samples() < offs.size - 1
+        assert_same_encoding(nat, ora, flat, offs, dropout=0.2, seed=9)
+    monkeypatch.setenv("TGX_CORUN", "0")
+    assert_same_encoding(nat, ora, flat, offs)
+    assert nat.last_encode_corun_cus() == 0

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : (PPL == 3 ? 4
         for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) score_tab[i] = Q.values[i];
         uint2* rw = reinterpret_cast<uint2*>(smem + Q.root_off);
         for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
+        if (Q.started && threadIdx.x == 0u) __hip_atomic_fetch_add(Q.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
     }
     const __amdgpu_buffer_rsrc_t cold_values = values;
@@ -1046,12 +1047,13 @@ hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uin
     return hipGetLastError();
 }
 
-hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, bool long_tokens, int waves, uint32_t blocks, hipStream_t stream) {
-    const uint32_t lds = encode5_lds_layout(q.n_hot, long_tokens, waves, ppl, &q.list_off, &q.root_off, &q.idx_off);
+hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, bool long_tokens, int waves, uint32_t blocks, uint32_t min_lds, hipStream_t stream) {
+    uint32_t lds = encode5_lds_layout(q.n_hot, long_tokens, waves, ppl, &q.list_off, &q.root_off, &q.idx_off);
     if (lds > 160u * 1024u || q.n_hot > q.n_values || (!cold && q.n_hot != q.n_values) || (long_tokens && ppl != 4)) return hipErrorInvalidValue;
     encode5_fn fn = pick_encode5(p.dropout > 0.0, cold, ppl, long_tokens);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    if (lds < min_lds && min_lds <= 160u * 1024u) lds = min_lds;  // (a launch that wants its CUs to itself)
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), lds, stream, p, q);
     return hipGetLastError();
 }

@@ -45,6 +45,8 @@ struct Encode5Params {
     uint32_t list_off, root_off, idx_off;  // LDS layout (set by the launcher)
     uint32_t ctrl_off, ring_off, ring_slots;  // encode6_kernel: control words, ring of match-index buffers
     uint32_t pool;                            // encode6_kernel, COLD builds: pool entries per ring slot for values its walkers fetch (0: none)
+    unsigned int* started;                    // encode5_kernel: when not null, every block adds 1 here once it is resident (host-visible memory:
+                                              // the co-run launches the long-sample kernel only after all of them are)
 };
 
 struct CompactParams {
@@ -187,7 +189,8 @@ uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool, uint32_t* root_off, u
 uint32_t encode6_max_hot(uint32_t budget, uint32_t pool);
 uint32_t encode6_pool_total(uint32_t pool);  // pool entries of a block (index space they take)
 hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream);
-hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, bool long_tokens, int waves, uint32_t blocks, hipStream_t stream);
+hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, bool long_tokens, int waves, uint32_t blocks,
+                          uint32_t min_lds, hipStream_t stream);
 hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted, hipStream_t stream);   // encode2.hip
 hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream);
 hipError_t launch_encode4l(const EncodeParams& p, uint32_t num_cus, hipStream_t stream);  // encode4l.hip

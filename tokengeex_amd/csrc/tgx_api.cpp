@@ -181,6 +181,9 @@ struct tgx_model {
     unsigned long long* d_ctrl = nullptr;  // [0] work counter, [1] min failing sample
     unsigned long long* h_ctrl = nullptr;  // pinned: [0] err sample, [1] total tokens
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // encode6_kernel beside encode5_kernel (run_encode_kernel: co-run)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned int* h_started = nullptr;      // page-locked, device-visible: blocks of encode5_kernel that are resident (co-run)
     int num_cus = 0;
     int blocks_per_cu = 0;  // encode_kernel (one sample per wave)
     // E-step only (built on first use): trie of the reversed tokens
@@ -194,6 +197,7 @@ struct tgx_model {
     void* d_trie_rev_w = nullptr;   //   (linear-domain E-step, estep4l.hip)
     uint64_t last_long_samples = 0;    // samples the last pass gave a block of their own (encode6_kernel)
     uint64_t last_estep_pieces = 0;    // pieces the last E-step cut its snippets into (0: uncut)
+    uint32_t last_corun_cus = 0;       // CUs the long-sample kernel had to itself beside encode5_kernel in the last pass (0: one after the other)
     uint64_t last_redo_samples = 0;    // samples the last encode4l pass left to encode2_kernel
     int last_encode_waves_per_cu = 0;  // resident waves per CU of the last rows4 encode launch (self-check)
     bool estep_linear_ok = false;   // tables for the linear-domain E-step kernels exist
@@ -438,6 +442,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         const bool cold6 = n_hot6 < m->n_values;
         uint64_t n_long = 0;
+        uint32_t corun_cus = 0;  // CUs of encode6_kernel when both kernels run at once (0: one after the other)
         if (c->n_samples && !long_tokens && e6_usable) {  // (encode6_kernel walks 16 bytes)
             const auto count_ge = [&](uint64_t thr) {  // h_sorted_len descends: the long samples are a prefix of the order
                 return (uint64_t)(std::partition_point(c->h_sorted_len.begin(), c->h_sorted_len.end(),
@@ -464,8 +469,48 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                         n_long = k;
                     }
                 }
+                // Both kernels at once, each on CUs of its own: between ~200 and ~450 MiB neither wins alone — the
+                // long-sample kernel is bound by its eight relaxing rows per CU, encode5_kernel by the chains of the
+                // longest samples.  `corun_cus` CUs (two blocks each) take the samples of at least thr bytes, the others
+                // run encode5_kernel on the rest; its blocks are launched first and ask for more than half of a CU's
+                // LDS, so no block of the other kernel shares their CU.  Estimates: a long-sample row does
+                // 1 / 0.0369 us (0.042 us with cold values) per byte, a CU 55 (46) GB/s / 256; encode5_kernel 0.12 us
+                // per byte of chain (measured beside the other kernel) and 70 GB/s x its share of the CUs.
+                const double c6 = cold6 ? 0.042e-6 : 0.0369e-6, r6 = (cold6 ? 46e9 : 55e9) / (double)m->num_cus;
+                double best_co = best * 0.9;
+                uint64_t k_co = 0;
+                static const uint64_t thrs[] = {8192, 12288, 16384, 24576, 32768, 40960, 49152};
+                static const uint32_t shares[] = {32, 48, 64, 96, 128, 160, 192};
+                // (only when encode5_kernel keeps every value in LDS on its few waves: its COLD builds are bound by the
+                // chains of mid-length samples at twice the estimate — profiles/r03/p_corun_sweep*.txt)
+                const bool corun_off = (knob("TGX_CORUN") && atoi(knob("TGX_CORUN")) == 0) ||
+                                       m->n_values > tgx::encode5_max_hot(false, 8, 4, 160u * 1024u);
+                for (uint64_t thr : thrs) {
+                    if (corun_off || thr > c->max_len || e6_bpc != 2) break;
+                    const uint64_t k = count_ge(thr);
+                    if (!k || k >= c->n_samples) continue;
+                    const double bytes_long = (double)c->h_sorted_cum[k - 1];
+                    const double r_max = (double)c->h_sorted_len[k], r_bytes = N - bytes_long;
+                    for (uint32_t X : shares) {
+                        if ((int)X >= m->num_cus) break;
+                        const double t6 = std::max((double)c->h_sorted_len[0] * c6, bytes_long / (X * r6)) + 20e-6;
+                        const double t5 = std::max(r_max * 0.12e-6, r_bytes / ((double)(m->num_cus - (int)X) / (double)m->num_cus * 70e9));
+                        const double t = std::max(t5, t6);
+                        if (t < best_co) {
+                            best_co = t;
+                            k_co = k;
+                            corun_cus = X;
+                        }
+                    }
+                }
+                if (corun_cus) n_long = k_co;
+            }
+            if (const char* e = knob("TGX_CORUN")) {  // forces the share of the long-sample kernel (0: no co-run)
+                const int v = atoi(e);
+                corun_cus = (v > 0 && v < m->num_cus && n_long > 0 && n_long < c->n_samples && e6_bpc == 2) ? (uint32_t)v : 0u;
             }
         }
+        const int cus5 = m->num_cus - (int)corun_cus;  // CUs of encode5_kernel
         // what is left for encode5_kernel: the samples from n_long on in the longest-first order
         const uint64_t rest_n = c->n_samples - n_long;
         const uint64_t rest_bytes = c->n_bytes - (n_long ? c->h_sorted_cum[n_long - 1] : 0);
@@ -503,7 +548,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         int balance_waves = 0;
         if (rest_max > 0) {
             const uint64_t rows_bal = (rest_bytes + rest_max - 1) / rest_max;
-            const uint64_t wb = (rows_bal + 4ull * (uint64_t)m->num_cus - 1) / (4ull * (uint64_t)m->num_cus);
+            const uint64_t wb = (rows_bal + 4ull * (uint64_t)cus5 - 1) / (4ull * (uint64_t)cus5);
             if (wb <= 10) {
                 balance_waves = (int)std::max<uint64_t>(4, wb);
                 ppl = 4;
@@ -534,7 +579,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         if (balance_waves > 0 && ppl == 4 && bpc == 1) waves = std::min(waves, balance_waves);
         {
-            const uint64_t rows_wanted = (c->n_samples + (uint64_t)m->num_cus * bpc - 1) / ((uint64_t)m->num_cus * bpc);
+            const uint64_t rows_wanted = (rest_n + (uint64_t)cus5 * bpc - 1) / ((uint64_t)cus5 * bpc);
             waves = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)waves, (rows_wanted + 3) / 4));
         }
         if (const char* e = knob("TGX_WAVES")) {
@@ -553,7 +598,7 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         m->last_encode_waves_per_cu = std::min(bpc, per_simd / ((waves + 3) / 4)) * waves;
         const uint64_t rows_per_block = 4 * (uint64_t)waves;
         const uint32_t blocks5 = (uint32_t)std::max<uint64_t>(
-            1, std::min<uint64_t>((c->n_samples + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus * bpc));
+            1, std::min<uint64_t>((rest_n + rows_per_block - 1) / rows_per_block, (uint64_t)cus5 * bpc));
         tgx::Encode5Params q{};
         q.trie8 = m->d_trie8;
         q.trie_bytes = (uint32_t)(m->flat.table.size() * sizeof(tgx::Trie8Rec));
@@ -568,18 +613,35 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             if (const char* e = knob("TGX_CLAIM_CHUNK")) q.claim_chunk = (uint32_t)std::min(64, std::max(1, atoi(e)));
         }
         m->last_long_samples = n_long;
+        m->last_corun_cus = n_long ? corun_cus : 0u;
+        tgx::EncodeParams p6 = p;
+        tgx::Encode5Params q6 = q;
+        uint32_t blocks6 = 0;
         if (n_long) {
-            tgx::EncodeParams p6 = p;
             p6.n_samples = n_long;
             // four samples per block (one per row of its relaxing wave); 13 waves of 64 registers: two blocks per CU
-            const uint32_t blocks6 = (uint32_t)std::min<uint64_t>((n_long + 3) / 4, (uint64_t)m->num_cus * (uint64_t)e6_bpc);
-            time_begin(m, "encode6_kernel");
-            tgx::Encode5Params q6 = q;
+            blocks6 = (uint32_t)std::min<uint64_t>((n_long + 3) / 4, (uint64_t)(corun_cus ? (int)corun_cus : m->num_cus) * (uint64_t)e6_bpc);
             q6.n_hot = n_hot6;
             q6.pool = cold6 ? pool6 : 0u;
-            HIP_TRY(tgx::launch_encode6(p6, q6, cold6, blocks6, m->stream));
-            time_end(m);
-            HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode5_kernel
+            if (!corun_cus) {
+                time_begin(m, "encode6_kernel");
+                HIP_TRY(tgx::launch_encode6(p6, q6, cold6, blocks6, m->stream));
+                time_end(m);
+                HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));  // the work queue, for encode5_kernel
+            } else {
+                if (!m->stream2) {
+                    HIP_TRY(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+                    HIP_TRY(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+                    HIP_TRY(hipHostMalloc((void**)&m->h_started, 64, hipHostMallocMapped | hipHostMallocPortable));
+                }
+                *reinterpret_cast<volatile unsigned int*>(m->h_started) = 0u;
+                q.started = m->h_started;
+                p6.queue = m->d_ctrl + 2;  // a work queue of its own
+                HIP_TRY(hipMemsetAsync(m->d_ctrl + 2, 0x00, 8, m->stream));
+                HIP_TRY(hipEventRecord(m->ev_fork, m->stream));
+                HIP_TRY(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+            }
             p.order = c->d_order + n_long;
             p.n_samples = c->n_samples - n_long;
         }
@@ -602,7 +664,8 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 p.redo_list = c->d_counts;  // free until the trace writes the token counts
                 HIP_TRY(hipMemsetAsync(m->d_ctrl + 6, 0x00, 8, m->stream));
             }
-            const hipError_t le = tgx::launch_encode5(p, q, cold, ppl, long_tokens, waves, blocks5, m->stream);
+            // (co-run: more than half of the CU's LDS, so that no block of the long-sample kernel shares the CU)
+            const hipError_t le = tgx::launch_encode5(p, q, cold, ppl, long_tokens, waves, blocks5, corun_cus && n_long ? 84u * 1024u : 0u, m->stream);
             if (le != hipSuccess) {
                 if (d_stamps5) {
                     (void)hipStreamSynchronize(m->stream);
@@ -611,7 +674,38 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 return fail(TGX_ERR_DEVICE, "encode5 launch failed: %s", hipGetErrorString(le));
             }
         }
+        bool joined = false, joined_slot = false;
+        if (n_long && corun_cus) {  // the long-sample kernel beside it, on the second stream, with a timing slot of its own
+            const bool slot = m->n_timed + 1 < kMaxTimed;
+            if (slot) {
+                KernelTime& tb = m->timed[m->n_timed + 1];
+                tb.name = "encode6_kernel";
+                tb.used = true;
+                (void)hipEventRecord(tb.start, m->stream2);
+            }
+            {   // the long-sample kernel's blocks must find the CUs of encode5_kernel's blocks taken: wait (at most 2 ms)
+                // until every one of those has reported itself resident
+                const auto t0 = std::chrono::steady_clock::now();
+                volatile unsigned int* started = m->h_started;
+                while (*started < blocks5 && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2)) {
+                }
+            }
+            const hipError_t l6 = tgx::launch_encode6(p6, q6, cold6, blocks6, m->stream2);
+            if (slot) (void)hipEventRecord(m->timed[m->n_timed + 1].stop, m->stream2);
+            (void)hipEventRecord(m->ev_join, m->stream2);
+            if (l6 != hipSuccess) {
+                (void)hipStreamSynchronize(m->stream);
+                (void)hipStreamSynchronize(m->stream2);
+                return fail(TGX_ERR_DEVICE, "encode6 launch failed: %s", hipGetErrorString(l6));
+            }
+            joined = true;
+            joined_slot = slot;
+        }
         time_end(m);
+        if (joined) {
+            if (joined_slot) m->n_timed++;
+            HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_join, 0));  // the trace needs both kernels' back-pointers
+        }
         if (d_stamps5) {  // diagnostic: mean ticks per iteration and phase over all waves
             std::vector<unsigned long long> h(n_stamp_waves5 * 8);
             const bool ok = hipStreamSynchronize(m->stream) == hipSuccess &&
@@ -1077,6 +1171,10 @@ void tgx_model_destroy(tgx_model* m) {
     if (m->d_tokid) (void)hipFree(m->d_tokid);
     if (m->d_ctrl) (void)hipFree(m->d_ctrl);
     if (m->h_ctrl) (void)hipHostFree(m->h_ctrl);
+    if (m->stream2) (void)hipStreamDestroy(m->stream2);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->h_started) (void)hipHostFree(m->h_started);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -2430,6 +2528,7 @@ uint64_t tgx_last_algorithmic_bytes(const tgx_model* m) { return m ? m->last_alg
 uint64_t tgx_last_encode_redo_samples(const tgx_model* m) { return m ? m->last_redo_samples : 0; }
 uint64_t tgx_last_encode_long_samples(const tgx_model* m) { return m ? m->last_long_samples : 0; }
 uint64_t tgx_last_estep_pieces(const tgx_model* m) { return m ? m->last_estep_pieces : 0; }
+uint32_t tgx_last_encode_corun_cus(const tgx_model* m) { return m ? m->last_corun_cus : 0; }
 uint32_t tgx_model_score_values(const tgx_model* m) { return m && m->have_trie8 ? m->n_values : 0u; }
 uint32_t tgx_last_encode_hot_values(const tgx_model* m) { return m ? m->last_n_hot : 0u; }
 
