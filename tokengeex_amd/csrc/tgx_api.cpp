@@ -453,11 +453,14 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 if (thr) n_long = count_ge(thr);
             } else {
                 const double N = (double)c->n_bytes;
+                // encode5_kernel's chain of a long sample on the few waves such a batch gets: 7.1 ms per 64 KiB with every
+                // value in LDS, 8.7 ms with the COLD build (profiles/r03/l_*, o_*)
+                const double c5 = m->n_values > tgx::encode5_max_hot(false, 8, 4, 160u * 1024u) ? 0.135e-6 : 0.108e-6;
                 auto cost = [&](uint64_t k) {  // the k longest samples to encode6_kernel
                     const double bytes_long = k ? (double)c->h_sorted_cum[k - 1] : 0.0;
                     const double t6 = k ? std::max((double)c->h_sorted_len[0] * (cold6 ? 0.042e-6 : 0.0369e-6), bytes_long / (cold6 ? 46e9 : 55e9)) + 20e-6 : 0.0;
                     const double rest_max = k < c->n_samples ? (double)c->h_sorted_len[k] : 0.0;
-                    const double t5 = std::max(rest_max * 0.104e-6, (N - bytes_long) / 88e9);
+                    const double t5 = std::max(rest_max * c5, (N - bytes_long) / 88e9);
                     return t6 + t5;
                 };
                 double best = cost(0);
