@@ -44,7 +44,7 @@ for case in range(cases):
     flat, offs = tgx.pack(texts)
     dropout = float(rng.choice([0.0, 0.0, 0.1, 0.5, 1.0]))
     sd = int(rng.integers(0, 1 << 62))
-    for k in ("TGX_PPL", "TGX_EPPL", "TGX_PATH", "TGX_LONG_THRESHOLD", "TGX_E5_HOT", "TGX_E6_POOL", "TGX_E2E_CHUNK_MB", "TGX_ESTEP_PIECES", "TGX_ESTEP_WINDOW"):
+    for k in ("TGX_PPL", "TGX_EPPL", "TGX_PATH", "TGX_LONG_THRESHOLD", "TGX_E5_HOT", "TGX_E6_POOL", "TGX_E2E_CHUNK_MB", "TGX_ESTEP_PIECES", "TGX_ESTEP_WINDOW", "TGX_CORUN"):
         os.environ.pop(k, None)
     if rng.random() < 0.6: os.environ["TGX_PPL"] = str(int(rng.choice([1, 2, 4])))
     if rng.random() < 0.6: os.environ["TGX_EPPL"] = str(int(rng.choice([1, 2, 4])))
@@ -52,6 +52,8 @@ for case in range(cases):
     # through the pools), pool size (overflow -> redo pass)
     if rng.random() < 0.5: os.environ["TGX_PATH"] = str(rng.choice(["rows4", "rows5"]))
     if rng.random() < 0.5: os.environ["TGX_LONG_THRESHOLD"] = str(int(rng.choice([0, 1, 100, 1000, 30000])))
+    # round 3: both encode kernels at once (needs a threshold that leaves samples on both sides)
+    if os.environ.get("TGX_LONG_THRESHOLD") in ("100", "1000") and rng.random() < 0.6: os.environ["TGX_CORUN"] = str(int(rng.choice([16, 96, 200])))
     if rng.random() < 0.4: os.environ["TGX_E5_HOT"] = str(int(rng.choice([0, 3, 40, 500])))
     if rng.random() < 0.3: os.environ["TGX_E6_POOL"] = str(int(rng.choice([0, 4, 16, 128])))
     # round 3: the E-step on pieces (snippets cut where no match crosses), small windows
@@ -59,7 +61,7 @@ for case in range(cases):
         os.environ["TGX_ESTEP_PIECES"] = "1"
         os.environ["TGX_ESTEP_WINDOW"] = str(int(rng.choice([256, 512, 2048])))
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
-    tag = f"case {case} max_len={max_len} all_bytes={all_bytes} V={len(toks)} S={len(texts)} N={flat.size} dropout={dropout} env={os.environ.get('TGX_PPL')}/{os.environ.get('TGX_EPPL')}/{os.environ.get('TGX_PATH')}/{os.environ.get('TGX_LONG_THRESHOLD')}/{os.environ.get('TGX_E5_HOT')}/{os.environ.get('TGX_E6_POOL')}/{os.environ.get('TGX_ESTEP_PIECES')}/{os.environ.get('TGX_ESTEP_WINDOW')}"
+    tag = f"case {case} max_len={max_len} all_bytes={all_bytes} V={len(toks)} S={len(texts)} N={flat.size} dropout={dropout} env={os.environ.get('TGX_PPL')}/{os.environ.get('TGX_EPPL')}/{os.environ.get('TGX_PATH')}/{os.environ.get('TGX_LONG_THRESHOLD')}/{os.environ.get('TGX_E5_HOT')}/{os.environ.get('TGX_E6_POOL')}/{os.environ.get('TGX_ESTEP_PIECES')}/{os.environ.get('TGX_ESTEP_WINDOW')}/{os.environ.get('TGX_CORUN')}"
     try:
         want_ids, want_offs = ora.encode_batch_flat(flat, offs, dropout, sd, threads=8)
         want_err = None
