@@ -400,3 +400,36 @@ def test_estep_pieces_by_default_on_a_chain_bound_batch():
     corpus = tgx.NativeCorpus(f2, o2)
     nat.estep(corpus)
     assert nat.last_estep_pieces() == 0
+
+
+# ---- round 3: the forward sweep on the 8-byte ranked records (encode5.hip: estep5_fwd_kernel) -------------------------
+
+@pytest.mark.parametrize("eppl,hot", [(None, None), ("1", None), ("2", None), ("3", "300"), ("4", "0"), ("4", None)])
+def test_estep_forward_sweep_on_ranked_records(monkeypatch, eppl, hot):
+    """estep5_fwd_kernel (encode5_kernel's staggered walk and 2-byte match indices, w = exp(score value) by rank in LDS or
+    read from L2) against the oracle and against estep4l_fwd_kernel (TGX_ESTEP_FWD=rows4): same matches, same weights,
+    same steps, so the two agree to the rounding of the backward kernel's unordered sums; every positions-per-lane
+    build, tables smaller than the vocabulary's values (COLD builds), dropout, pieces, distinct scores."""
+    if eppl:
+        monkeypatch.setenv("TGX_EPPL", eppl)
+    if hot:
+        monkeypatch.setenv("TGX_E5_HOT", hot)
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 8000, 16, seed_offset=81, max_len=30000)
+    rng = np.random.default_rng(31)
+    for sc in (scores, np.asarray(scores) + rng.uniform(-0.3, 0.3, len(toks))):
+        nat, ora = _pair(toks, sc)
+        got, gz = _check_estep(nat, ora, flat, offs)
+        assert "estep5_fwd_kernel" in nat.last_kernel_times()
+        _check_estep(nat, ora, flat, offs, dropout=0.2, seed=5)
+        monkeypatch.setenv("TGX_ESTEP_PIECES", "1")
+        monkeypatch.setenv("TGX_ESTEP_WINDOW", "512")
+        _check_estep(nat, ora, flat, offs)
+        monkeypatch.delenv("TGX_ESTEP_PIECES")
+        monkeypatch.delenv("TGX_ESTEP_WINDOW")
+        monkeypatch.setenv("TGX_ESTEP_FWD", "rows4")
+        corpus = tgx.NativeCorpus(flat, offs)
+        old, oz = nat.estep(corpus)
+        assert "estep4l_fwd_kernel" in nat.last_kernel_times() and "estep5_fwd_kernel" not in nat.last_kernel_times()
+        np.testing.assert_allclose(got, old, rtol=1e-11, atol=1e-13)
+        assert abs(gz - oz) <= 1e-13 * abs(oz)
+        monkeypatch.delenv("TGX_ESTEP_FWD")

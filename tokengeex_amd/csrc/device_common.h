@@ -248,4 +248,25 @@ __device__ __forceinline__ uint64_t tok_hash64_long_dev(const uint32_t* w, uint3
 }
 
 
+// ---- linear-domain E-step (estep4l.hip, encode5.hip: estep5_fwd_kernel) ----
+// exponent of the largest of a row's 16 accumulators (all lanes of the row get it); zeros do not count
+__device__ __forceinline__ int row_max_exponent(double acc) {
+    int e = (acc == 0.0) ? -100000 : __builtin_amdgcn_frexp_exp(acc);  // acc = m * 2^e, 0.5 <= |m| < 1
+    e = max(e, __builtin_amdgcn_update_dpp(e, e, 0x121, 0xF, 0xF, false));  // row_ror:1
+    e = max(e, __builtin_amdgcn_update_dpp(e, e, 0x122, 0xF, 0xF, false));  // row_ror:2
+    e = max(e, __builtin_amdgcn_update_dpp(e, e, 0x124, 0xF, 0xF, false));  // row_ror:4
+    e = max(e, __builtin_amdgcn_update_dpp(e, e, 0x128, 0xF, 0xF, false));  // row_ror:8
+    return e;
+}
+
+template <int U>
+__device__ __forceinline__ void e4l_fwd_step(double sv, double& acc, double& fin) {
+    constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
+    fin = sel_f64(MU, acc, fin);             // a[p0 + U] is final now
+    const double best = row_bcast_f64<U>(acc);
+    const double cand = best * sv;           // sv = 0 where no token of this length starts at p0 + U
+    acc = sel_f64(MU, cand, acc + cand);     // lane U starts accumulating position p0 + U + 16
+}
+
+
 }  // namespace tgx

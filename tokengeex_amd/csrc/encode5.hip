@@ -72,6 +72,7 @@ struct WalkCtx {
     uint32_t s, l32;
     double dropout;
     uint64_t seed;
+    bool estep_rule = false;  // the keep rule of populate_nodes (model.rs:48: skipped iff rand < dropout) instead of encode's (model.rs:100)
 };
 
 // RES walks (the walker waves of encode6_kernel, COLD builds): a match whose value is not in the block's LDS copy is
@@ -130,7 +131,10 @@ struct Walk5 {
             const uint32_t rank = rec[g].y & 0xFFFFu;  // 0: no token ends here
             bool term = alive[g] && rank != 0u;
             if (DROPOUT) {  // model.rs:100: kept iff len <= 1 || dropout < rand
-                if (term && d >= 1) term = W.dropout < dropout_u01(W.seed, W.s, pg[g], (uint32_t)d + 1u);
+                if (term && d >= 1) {
+                    const double u01 = dropout_u01(W.seed, W.s, pg[g], (uint32_t)d + 1u);
+                    term = W.estep_rule ? !(u01 < W.dropout) : (W.dropout < u01);
+                }
             }
             if (RES) {
                 if (D > 0) R.complete();  // the cold match of the depth before: its value was requested ahead of this depth's record
@@ -968,6 +972,234 @@ __global__ __launch_bounds__(64 * (1 + 4 * kE6Walkers), 8) void encode6_kernel(E
             if (lane == 0u) lds_store(&ctrl->walk_done[slot], t + 1u);
         }
     }
+}
+
+
+// ---- estep5_fwd_kernel: the forward sweep of the E-step (src/lattice.rs:259-291) on this file's structure ----------
+// estep4l_fwd_kernel (estep4l.hip) walks 16-byte records at one position per lane and carries f64 weights through
+// an 8 KiB match buffer per wave.  For vocabularies that have 8-byte records (at most 65 535 distinct score values,
+// tokens of at most 16 bytes) the forward sweep is this kernel instead: encode5_kernel's staggered walk over the
+// ranked records and its 2 KiB match-index buffers, the table holding w = exp(score value) by rank (entry 0 = 0: "no
+// token"), and estep4l_fwd_kernel's steps and epilogue — a[p] = sum a[start] * w in the linear domain with a power-of-
+// two exponent per block of 16 positions, alpha / alpha_exp / z written in its layout, the same range check.  Same
+// matches, same weights (exp of the same doubles, taken on the host), same operations in the same order: the arrays
+// are bit-identical to estep4l_fwd_kernel's (tests/test_estep_pairs_gpu.py), the backward kernel is unchanged.
+template <bool DROPOUT, bool COLD, int PPL>
+__global__ __launch_bounds__(1024, (PPL == 4 ? 1 : 4)) void estep5_fwd_kernel(Estep4Params P, Encode5Params Q) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr uint32_t LM = 16;
+    constexpr uint32_t SPAN = 16u * PPL;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t l = lane & 15u, r = lane >> 4;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint2* __restrict__ trie = reinterpret_cast<const uint2*>(Q.trie8);
+    const __amdgpu_buffer_rsrc_t trie_b = make_rsrc(Q.trie8, Q.trie_bytes);
+    const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+    double* const w_tab = reinterpret_cast<double*>(smem);  // [0] = 0.0 ("no token"), [r] = exp(score value of rank r)
+    const uint32_t hot_bytes = 8u * (Q.n_hot + 1u);
+    const __amdgpu_buffer_rsrc_t cold_values = make_rsrc(reinterpret_cast<const unsigned char*>(Q.values) + hot_bytes, 8u * (Q.n_values - Q.n_hot));
+    const uint2* rootc = reinterpret_cast<const uint2*>(smem + Q.root_off);
+    unsigned char* wbase = smem + Q.idx_off + (size_t)wave * (PPL * kE5GroupBytes);
+    {
+        for (uint32_t i = threadIdx.x; i <= Q.n_hot; i += blockDim.x) w_tab[i] = Q.values[i];
+        uint2* rw = reinterpret_cast<uint2*>(smem + Q.root_off);
+        for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) rw[i] = trie[(Q.root_base & ~255u) + i];
+        __syncthreads();
+    }
+    uint32_t s = 0, n = 0, p0 = 0, smp = 0;
+    uint64_t beg = 0, sbase = 0, ebase = 0;
+    bool live = false, need_new = true;
+    double acc = 0.0;
+    int erow = 0;  // alpha_true = acc * 2^erow for every accumulator of the row
+    double zsum = 0.0;
+    uint32_t wn[4 * PPL + 1];
+#pragma unroll
+    for (int q = 0; q <= 4 * PPL; ++q) wn[q] = 0;
+    const uint32_t my_col = r * kE5RowStride + ((l - 1u) & 15u) * 32u;
+    const uint32_t wbase_off = lds0 + Q.idx_off + wave * (PPL * kE5GroupBytes);
+    const uint32_t wr_off = wbase_off + r * kE5RowStride + l * 2u;
+    const uint32_t col_off = wbase_off + my_col;
+    uint64_t local_next = 0, local_end = 0;
+    for (;;) {
+        {
+            uint64_t k = ~0ull;
+            const bool have_local = need_new && local_next < local_end;
+            if (have_local) k = local_next++;
+            const uint64_t kc = claim_rows_chunk(P.queue_fwd, need_new && !have_local, r, Q.claim_chunk);
+            if (need_new && !have_local) {
+                k = kc;
+                local_next = kc + 1u;
+                local_end = kc + Q.claim_chunk;
+            }
+            if (need_new) {
+                live = k < P.n_snips;
+                if (live) {
+                    s = P.order[k];
+                    beg = P.soffs[s];
+                    n = (uint32_t)(P.soffs[s + 1] - beg);
+                    ebase = (beg >> 4) + s;
+                    if (DROPOUT) {
+                        smp = P.snip_sample[s];
+                        sbase = P.snip_base[s];
+                    }
+                }
+                p0 = 0;
+                acc = (l == 0u) ? 1.0 : 0.0;  // BOS (lattice.rs:96-101, 267)
+                erow = 0;
+            }
+        }
+        const bool fresh_row = need_new;
+        need_new = false;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+
+        // ---- text window, reset of this lane's columns (as encode5_kernel)
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(P.text + (live ? beg + p0 + l : 0));
+        const uint32_t sh = (uint32_t)(addr & 3u);
+        const uint32_t* __restrict__ wp = reinterpret_cast<const uint32_t*>(addr & ~uintptr_t(3));
+        uint32_t w[4 * PPL + 1];
+        if (fresh_row) {
+#pragma unroll
+            for (int q = 0; q <= 4 * PPL; ++q) w[q] = wp[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q <= 4 * PPL; ++q) w[q] = wn[q];
+        }
+        uint32_t bytes[PPL][4];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bytes[g][q] = __builtin_amdgcn_alignbyte(w[4 * g + q + 1], w[4 * g + q], sh);
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            uint4* mine = reinterpret_cast<uint4*>(wbase + g * kE5GroupBytes + my_col);
+            mine[0] = make_uint4(0, 0, 0, 0);
+            mine[1] = make_uint4(0, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- match
+        uint32_t pg[PPL], pgh[PPL], maxd[PPL], wlane[PPL], c[PPL];
+        bool alive[PPL];
+        uint2 rec[PPL];
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            pg[g] = p0 + 16u * g + l;
+            pgh[g] = (uint32_t)sbase + pg[g];  // position in the SAMPLE: what the keep rule hashes (samples < 4 GiB: host)
+            const uint32_t rem = (live && pg[g] < n) ? (n - pg[g]) : 0u;
+            maxd[g] = rem < LM ? rem : LM;
+            alive[g] = maxd[g] > 0;
+            wlane[g] = wr_off + g * kE5GroupBytes;
+            c[g] = bytes[g][0] & 0xFFu;
+            rec[g] = rootc[(Q.root_base ^ c[g]) & 255u];
+        }
+        {
+            uint32_t l32 = l * 32u;
+            asm volatile("" : "+v"(l32));
+            WalkCtx<PPL> W{trie_b, smp, l32, P.dropout, P.seed, true};
+            Res5 no_res{};
+            Walk5<DROPOUT, false, false, PPL, 0>::run(W, no_res, bytes, maxd, pgh, wlane, alive, rec, c);
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // the following trip's text window lands while the steps run
+            const uint32_t* __restrict__ np = wp + 4 * PPL;
+#pragma unroll
+            for (int q = 0; q <= 4 * PPL; ++q) wn[q] = np[q];
+        }
+
+        // ---- forward recursion (estep4l_fwd_kernel's steps): 16 static steps per group of 16 positions, then the row is
+        // rescaled; the values of a group are stored under the exponent in effect while they were finalised
+#pragma unroll
+        for (int g = 0; g < PPL; ++g) {
+            uint32_t iw[8];
+            {
+                const u32x4_t ia = lds_ld<u32x4_t>(col_off + g * kE5GroupBytes), ib = lds_ld<u32x4_t>(col_off + g * kE5GroupBytes + 16u);
+                iw[0] = ia.x; iw[1] = ia.y; iw[2] = ia.z; iw[3] = ia.w;
+                iw[4] = ib.x; iw[5] = ib.y; iw[6] = ib.z; iw[7] = ib.w;
+            }
+            double sv[8], sw[8];
+            if (COLD) {
+                e5_scores_cold<8>(lds0, cold_values, iw, 0, hot_bytes, sv);
+                e5_scores_cold<8>(lds0, cold_values, iw, 8, hot_bytes, sw);
+            } else {
+                u32x2_t sa[8], sb[8];
+                e5_scores_issue<8>(lds0, iw, 0, sa);
+                e5_scores_issue<8>(lds0, iw, 8, sb);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    sv[u] = e5_score_value(sa[u]);
+                    sw[u] = e5_score_value(sb[u]);
+                }
+            }
+            double fin = 0.0;
+            e4l_fwd_step<0>(sv[0], acc, fin);
+            e4l_fwd_step<1>(sv[1], acc, fin);
+            e4l_fwd_step<2>(sv[2], acc, fin);
+            e4l_fwd_step<3>(sv[3], acc, fin);
+            e4l_fwd_step<4>(sv[4], acc, fin);
+            e4l_fwd_step<5>(sv[5], acc, fin);
+            e4l_fwd_step<6>(sv[6], acc, fin);
+            e4l_fwd_step<7>(sv[7], acc, fin);
+            e4l_fwd_step<8>(sw[0], acc, fin);
+            e4l_fwd_step<9>(sw[1], acc, fin);
+            e4l_fwd_step<10>(sw[2], acc, fin);
+            e4l_fwd_step<11>(sw[3], acc, fin);
+            e4l_fwd_step<12>(sw[4], acc, fin);
+            e4l_fwd_step<13>(sw[5], acc, fin);
+            e4l_fwd_step<14>(sw[6], acc, fin);
+            e4l_fwd_step<15>(sw[7], acc, fin);
+            if (live && pg[g] <= n) {
+                P.alpha[beg + s + pg[g]] = fin;
+                // a position nothing was pushed to (lattice.rs:255), an underflow or an overflow: the pass belongs to
+                // the log-domain kernels
+                if (!(fin > 0.0 && fin <= 1.7976931348623157e308)) atomicMax(P.range_flag, 1ULL);
+                if (l == 0u) P.alpha_exp[ebase + (pg[g] >> 4)] = erow;
+                if (pg[g] == n) {  // z = log alpha_true[n] (lattice.rs:290-291)
+                    const double z = log(fin) + (double)erow * 0.6931471805599453;
+                    P.zarr[s] = z;
+                    zsum += z;
+                    const double az = fabs(z);  // !z.is_normal() panics in the reference (prune.rs:90-96)
+                    if (!(az >= 2.2250738585072014e-308 && az <= 1.7976931348623157e308)) atomicMin(P.err_snip, (unsigned long long)s);
+                }
+            }
+            const int e = row_max_exponent(acc);
+            if (e > -100000) {
+                acc = ldexp(acc, -e);
+                erow += e;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (live) {
+            if (n - p0 < SPAN) need_new = true;  // position n lies in this trip: the snippet is done
+            else p0 += SPAN;
+        }
+    }
+    if (zsum != 0.0) atomicAdd(P.logz_sum, zsum);
+}
+
+typedef void (*estep5_fn)(Estep4Params, Encode5Params);
+static estep5_fn pick_estep5(bool dropout, bool cold, int ppl) {
+#define TGX_E5F(D, C)                                                                        \
+    (ppl == 1 ? estep5_fwd_kernel<D, C, 1> : ppl == 2 ? estep5_fwd_kernel<D, C, 2> : ppl == 3 ? estep5_fwd_kernel<D, C, 3> : estep5_fwd_kernel<D, C, 4>)
+    if (dropout) return cold ? TGX_E5F(true, true) : TGX_E5F(true, false);
+    return cold ? TGX_E5F(false, true) : TGX_E5F(false, false);
+#undef TGX_E5F
+}
+hipError_t estep5_waves_per_simd(bool dropout, bool cold, int ppl, int* out) {
+    hipFuncAttributes attr;
+    hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(pick_estep5(dropout, cold, ppl)));
+    if (e != hipSuccess) return e;
+    const int regs = (attr.numRegs + 7) & ~7;
+    *out = regs > 0 ? (512 / regs > 8 ? 8 : 512 / regs) : 8;
+    return hipSuccess;
+}
+hipError_t launch_estep5_fwd(const Estep4Params& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
+    const uint32_t lds = encode5_lds_layout(q.n_hot, false, waves, ppl, &q.list_off, &q.root_off, &q.idx_off);
+    if (lds > 160u * 1024u || q.n_hot > q.n_values || (!cold && q.n_hot != q.n_values) || ppl < 1 || ppl > 4) return hipErrorInvalidValue;
+    estep5_fn fn = pick_estep5(p.dropout > 0.0, cold, ppl);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(64u * (uint32_t)waves), lds, stream, p, q);
+    return hipGetLastError();
 }
 
 typedef void (*encode5_fn)(EncodeParams, Encode5Params);

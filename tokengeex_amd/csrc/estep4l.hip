@@ -36,16 +36,6 @@ namespace tgx {
 
 constexpr uint32_t kE4LEntries = 1024;  // 64 rows x 16 columns
 
-// exponent of the largest of a row's 16 accumulators (all lanes of the row get it); zeros do not count
-__device__ __forceinline__ int row_max_exponent(double acc) {
-    int e = (acc == 0.0) ? -100000 : __builtin_amdgcn_frexp_exp(acc);  // acc = m * 2^e, 0.5 <= |m| < 1
-    e = max(e, __builtin_amdgcn_update_dpp(e, e, 0x121, 0xF, 0xF, false));  // row_ror:1
-    e = max(e, __builtin_amdgcn_update_dpp(e, e, 0x122, 0xF, 0xF, false));  // row_ror:2
-    e = max(e, __builtin_amdgcn_update_dpp(e, e, 0x124, 0xF, 0xF, false));  // row_ror:4
-    e = max(e, __builtin_amdgcn_update_dpp(e, e, 0x128, 0xF, 0xF, false));  // row_ror:8
-    return e;
-}
-
 // ---- tokens of 17..32 bytes (vocabularies after `merge`): LONG = true builds ---------------------------------
 // Such tokens are rare matches, so the kernels keep their 16-column structure and add, per lane, a second
 // accumulator `far` for the position 17..32 ahead (the scheme of encode4l_kernel; sums commute, so no order
@@ -65,15 +55,6 @@ __device__ __forceinline__ void e4l_fwd_step_long(double sv, double& acc, double
     const double cand = best * sv;
     acc = sel_f64(MU, far, acc) + cand;      // lane U restarts from the long contributions to position p0 + U + 16
     far = sel_f64(MU, 0.0, far);             // its `far` now stands for position p0 + U + 32
-}
-
-template <int U>
-__device__ __forceinline__ void e4l_fwd_step(double sv, double& acc, double& fin) {
-    constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
-    fin = sel_f64(MU, acc, fin);             // a[p0 + U] is final now
-    const double best = row_bcast_f64<U>(acc);
-    const double cand = best * sv;           // sv = 0 where no token of this length starts at p0 + U
-    acc = sel_f64(MU, cand, acc + cand);     // lane U starts accumulating position p0 + U + 16
 }
 
 // Hot slots (P.n_hot): expected counts of the first (hottest-first order) slots of the reversed trie are summed in

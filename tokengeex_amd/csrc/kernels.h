@@ -188,6 +188,9 @@ hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, bool long_to
 uint32_t encode6_lds_layout(uint32_t n_hot, uint32_t pool, uint32_t* root_off, uint32_t* ctrl_off, uint32_t* ring_off);
 uint32_t encode6_max_hot(uint32_t budget, uint32_t pool);
 uint32_t encode6_pool_total(uint32_t pool);  // pool entries of a block (index space they take)
+// estep5_fwd_kernel (encode5.hip): the E-step's forward sweep over the 8-byte ranked records; q.values = exp(score value) by rank
+hipError_t estep5_waves_per_simd(bool dropout, bool cold, int ppl, int* out);
+hipError_t launch_estep5_fwd(const struct Estep4Params& p, Encode5Params q, bool cold, int ppl, int waves, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode6(const EncodeParams& p, Encode5Params q, bool cold, uint32_t blocks, hipStream_t stream);
 hipError_t launch_encode5(const EncodeParams& p, Encode5Params q, bool cold, int ppl, bool long_tokens, int waves, uint32_t blocks,
                           uint32_t min_lds, hipStream_t stream);

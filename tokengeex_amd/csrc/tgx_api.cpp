@@ -211,6 +211,9 @@ struct tgx_model {
     uint32_t last_n_hot = 0;           // values in the LDS copy of the last encode5 launch
     bool have_trie8 = false;
     bool encode_tables_ready = false;  // tokhash / trie8 built and uploaded (ensure_encode_tables)
+    bool estep_trie8_tried = false;    // ensure_estep_trie8 ran
+    bool have_wvalues = false;         // d_trie8 / d_wvalues are there for estep5_fwd_kernel
+    double* d_wvalues = nullptr;       // f64[n_values + 1]: [0] = 0, [r] = exp(score value of rank r)
     bool tokhash_host_built = false;   // m->tokhash was built beside the forward trie at creation
     int estep_blocks_per_cu = 0;
     KernelTime timed[kMaxTimed] = {};
@@ -1174,6 +1177,7 @@ void tgx_model_destroy(tgx_model* m) {
     if (m->d_tokid) (void)hipFree(m->d_tokid);
     if (m->d_ctrl) (void)hipFree(m->d_ctrl);
     if (m->h_ctrl) (void)hipHostFree(m->h_ctrl);
+    if (m->d_wvalues) (void)hipFree(m->d_wvalues);
     if (m->stream2) (void)hipStreamDestroy(m->stream2);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -2033,6 +2037,37 @@ static tgx_status ensure_reverse_trie(tgx_model* m) {
     return TGX_OK;
 }
 
+// The 8-byte ranked records and the table of w = exp(score value) by rank for estep5_fwd_kernel (encode5.hip): built at
+// the first E-step of a model whose vocabulary allows them (tokens of at most 16 bytes, finite scores, at most 65 535
+// distinct values, at most 2^21 slots); models created for E-step passes do not have the encode tables.
+static tgx_status ensure_estep_trie8(tgx_model* m) {
+    if (m->estep_trie8_tried) return TGX_OK;
+    m->estep_trie8_tried = true;
+    if (!(m->lm <= 16 && m->scores_finite && m->vocab_size && m->flat.table.size() <= tgx::kTrie8MaxSlots)) return TGX_OK;
+    tgx::Trie8 t8;
+    tgx::build_trie8(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), &t8);
+    if (!t8.ok) return TGX_OK;
+    const size_t ns = t8.rec.size(), nv = t8.values.size();
+    std::vector<double> w(nv);
+    w[0] = 0.0;  // "no token"
+    for (size_t r = 1; r < nv; r++) {
+        double v;
+        memcpy(&v, &t8.values[r], 8);
+        w[r] = std::exp(v);  // the same function of the same double as the weights of the 16-byte tables (upload_weights)
+    }
+    if (!m->d_trie8) HIP_TRY(hipMalloc(&m->d_trie8, ns * sizeof(tgx::Trie8Rec)));
+    if (!m->d_values) HIP_TRY(hipMalloc((void**)&m->d_values, nv * 8));
+    if (!m->d_wvalues) HIP_TRY(hipMalloc((void**)&m->d_wvalues, nv * 8));
+    HIP_TRY(hipMemcpy(m->d_trie8, t8.rec.data(), ns * sizeof(tgx::Trie8Rec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_values, t8.values.data(), nv * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_wvalues, w.data(), nv * 8, hipMemcpyHostToDevice));
+    m->n_values = (uint32_t)nv - 1u;
+    m->root_base8 = t8.root_base;
+    if (m->value_coverage.empty()) m->value_coverage = std::move(t8.coverage);
+    m->have_wvalues = true;
+    return TGX_OK;
+}
+
 // E-step on the four-snippets-per-wave kernels (estep4.hip).  Caller holds m->mu and has
 // built the reversed trie.
 // `fallback` (vocabularies with tokens of 17..32 bytes only): set when the linear-domain kernels cannot do the
@@ -2324,6 +2359,74 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             if (v == 1 || v == 2 || v == 4) eppl_fwd = eppl_bwd = v;
         }
     }
+    // Forward sweep on the 8-byte ranked records (encode5.hip: estep5_fwd_kernel) where the vocabulary has them; the
+    // geometry as for encode5_kernel: every w in LDS with four positions per lane on 16..13 waves, three on 13, two
+    // on 16, else three on 16 with the hottest in LDS (COLD build).  TGX_ESTEP_FWD=rows4 keeps estep4l_fwd_kernel.
+    bool use5f = false, cold5f = false;
+    int ppl5f = 4, waves5f = 16;
+    tgx::Encode5Params q5f{};
+    uint32_t blocks5f = 1;
+    if (linear && !long_tokens && c->max_len < (1ull << 32)) {
+        const char* ff = knob("TGX_ESTEP_FWD");
+        const char* fp = knob("TGX_PATH");  // (rows4 names the kernels over the 16-byte records, here as for encode)
+        if (!(ff && strcmp(ff, "rows4") == 0) && !(fp && strcmp(fp, "rows4") == 0)) {
+            const tgx_status est = ensure_estep_trie8(m);
+            if (est != TGX_OK) return cleanup(est);
+            use5f = m->have_wvalues;
+        }
+    }
+    if (use5f) {
+        const uint32_t budget = 160u * 1024u;
+        auto fits = [&](int waves, int ppl) { return m->n_values <= tgx::encode5_max_hot(false, waves, ppl, budget); };
+        if (fits(13, 4)) {
+            ppl5f = 4;
+            waves5f = 16;
+            while (!fits(waves5f, 4)) waves5f--;
+        } else if (fits(13, 3)) {
+            ppl5f = 3;
+            waves5f = 13;
+        } else if (fits(16, 2)) {
+            ppl5f = 2;
+            waves5f = 16;
+        } else {
+            ppl5f = 3;
+            waves5f = 16;
+        }
+        if (const char* e = knob("TGX_EPPL")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 4) ppl5f = v;
+        }
+        uint32_t n_hot = std::min(m->n_values, tgx::encode5_max_hot(false, waves5f, ppl5f, budget));
+        if (const char* e = knob("TGX_E5_HOT")) {
+            const int v = atoi(e);
+            if (v >= 0) n_hot = std::min(n_hot, (uint32_t)v);
+        }
+        cold5f = n_hot < m->n_values;
+        int per_simd = 0;
+        if (tgx::estep5_waves_per_simd(dropout > 0.0, cold5f, ppl5f, &per_simd) != hipSuccess) return cleanup(fail(TGX_ERR_DEVICE, "estep5 attribute query failed"));
+        waves5f = std::max(1, std::min(waves5f, per_simd * 4));
+        const uint64_t n_units = pieces ? pc.n : K;
+        {
+            const uint64_t rows_wanted = (n_units + (uint64_t)m->num_cus - 1) / (uint64_t)m->num_cus;
+            waves5f = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)waves5f, (rows_wanted + 3) / 4));
+        }
+        n_hot = std::min(m->n_values, tgx::encode5_max_hot(false, waves5f, ppl5f, budget));  // (fewer waves: more room)
+        if (const char* e = knob("TGX_E5_HOT")) {
+            const int v = atoi(e);
+            if (v >= 0) n_hot = std::min(n_hot, (uint32_t)v);
+        }
+        cold5f = n_hot < m->n_values;
+        q5f.trie8 = m->d_trie8;
+        q5f.trie_bytes = (uint32_t)(m->flat.table.size() * sizeof(tgx::Trie8Rec));
+        q5f.values = m->d_wvalues;
+        q5f.root_base = m->root_base8;
+        q5f.n_values = m->n_values;
+        q5f.n_hot = n_hot;
+        const uint64_t avg = n_units ? N / n_units : 0;
+        q5f.claim_chunk = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, 4096 / std::max<uint64_t>(1, avg)));
+        const uint64_t rows_per_block = 4ull * (uint64_t)waves5f;
+        blocks5f = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_units + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus));
+    }
     bool use_linear = linear;
     for (;;) {
         p.trie_fwd = use_linear ? m->d_trie_w : m->d_trie;
@@ -2339,10 +2442,12 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             hipMemsetAsync(d_z, 0, 256, m->stream) != hipSuccess ||
             hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "E-step queue reset failed"));
-        time_begin(m, use_linear ? "estep4l_fwd_kernel" : "estep4_fwd_kernel");
-        if ((use_linear ? tgx::launch_estep4l_fwd(p, eppl_fwd, long_tokens, (uint32_t)m->num_cus, m->stream)
-                        : tgx::launch_estep4_fwd(p, (uint32_t)m->num_cus, m->stream)) != hipSuccess)
-            return cleanup(fail(TGX_ERR_DEVICE, "estep4 forward launch failed"));
+        const bool fwd5 = use_linear && use5f;
+        time_begin(m, fwd5 ? "estep5_fwd_kernel" : (use_linear ? "estep4l_fwd_kernel" : "estep4_fwd_kernel"));
+        if ((fwd5 ? tgx::launch_estep5_fwd(p, q5f, cold5f, ppl5f, waves5f, blocks5f, m->stream)
+                  : (use_linear ? tgx::launch_estep4l_fwd(p, eppl_fwd, long_tokens, (uint32_t)m->num_cus, m->stream)
+                                : tgx::launch_estep4_fwd(p, (uint32_t)m->num_cus, m->stream))) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "E-step forward launch failed"));
         time_end(m);
         if (use_linear) {
             unsigned long long flag = 0;
