@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <unordered_set>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -2044,6 +2045,17 @@ static tgx_status ensure_estep_trie8(tgx_model* m) {
     if (m->estep_trie8_tried) return TGX_OK;
     m->estep_trie8_tried = true;
     if (!(m->lm <= 16 && m->scores_finite && m->vocab_size && m->flat.table.size() <= tgx::kTrie8MaxSlots)) return TGX_OK;
+    {   // more than 65 535 distinct values (every model of a prune run above that many tokens): known after a fraction
+        // of a millisecond, not after build_trie8 has sorted them
+        std::unordered_set<uint64_t> seen;
+        seen.reserve(1u << 17);
+        for (uint32_t i = 0; i < m->vocab_size && seen.size() <= tgx::kTrie8MaxValues; i++) {
+            uint64_t b;
+            memcpy(&b, &m->vocab_scores[i], 8);
+            seen.insert(b);
+        }
+        if (seen.size() > tgx::kTrie8MaxValues) return TGX_OK;
+    }
     tgx::Trie8 t8;
     tgx::build_trie8(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), &t8);
     if (!t8.ok) return TGX_OK;
