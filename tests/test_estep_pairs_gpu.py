@@ -418,6 +418,10 @@ def test_estep_forward_sweep_on_ranked_records(monkeypatch, eppl, hot):
     rng = np.random.default_rng(31)
     for sc in (scores, np.asarray(scores) + rng.uniform(-0.3, 0.3, len(toks))):
         nat, ora = _pair(toks, sc)
+        # a model's FIRST pass over a small corpus keeps estep4l_fwd_kernel (the tables cost more than they save there) ...
+        _check_estep(nat, ora, flat, offs)
+        assert "estep4l_fwd_kernel" in nat.last_kernel_times()
+        # ... its second pass builds them
         got, gz = _check_estep(nat, ora, flat, offs)
         assert "estep5_fwd_kernel" in nat.last_kernel_times()
         _check_estep(nat, ora, flat, offs, dropout=0.2, seed=5)

@@ -213,6 +213,7 @@ struct tgx_model {
     bool have_trie8 = false;
     bool encode_tables_ready = false;  // tokhash / trie8 built and uploaded (ensure_encode_tables)
     bool estep_trie8_tried = false;    // ensure_estep_trie8 ran
+    uint64_t estep_calls = 0;          // E-step passes this model has run (estep_rows4)
     bool have_wvalues = false;         // d_trie8 / d_wvalues are there for estep5_fwd_kernel
     double* d_wvalues = nullptr;       // f64[n_values + 1]: [0] = 0, [r] = exp(score value of rank r)
     bool tokhash_host_built = false;   // m->tokhash was built beside the forward trie at creation
@@ -2382,8 +2383,13 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         const char* ff = knob("TGX_ESTEP_FWD");
         const char* fp = knob("TGX_PATH");  // (rows4 names the kernels over the 16-byte records, here as for encode)
         if (!(ff && strcmp(ff, "rows4") == 0) && !(fp && strcmp(fp, "rows4") == 0)) {
-            const tgx_status est = ensure_estep_trie8(m);
-            if (est != TGX_OK) return cleanup(est);
+            // The tables cost ~80 ns of host time per token of the vocabulary, the kernel saves ~4.7 ms per GiB of text:
+            // a model that runs ONE pass over a small shard (prune makes a model per EM sub-iteration, src/prune.rs:48)
+            // is better off without them; a model's second pass, or a pass over enough text, builds them.
+            if (!m->estep_trie8_tried && (m->estep_calls >= 1 || ff != nullptr || (double)N * 4.7e-12 >= (double)m->vocab_size * 80e-9)) {
+                const tgx_status est = ensure_estep_trie8(m);
+                if (est != TGX_OK) return cleanup(est);
+            }
             use5f = m->have_wvalues;
         }
     }
@@ -2524,6 +2530,7 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         if (id != tgx::kNoToken) expected[id] += h[t];
     }
     if (logz_sum) *logz_sum = hz;
+    m->estep_calls++;
     return cleanup(TGX_OK);
 }
 
