@@ -66,17 +66,19 @@ __device__ __forceinline__ void e4l_fwd_step_long(double sv, double& acc, double
 // trie record in HBM for a cold slot), which leaves room for 7 000 hot slots instead of 2 000.
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
+// (cs_cur, cs_nxt: a[p] / a[n] of the lane's two start positions, already scaled by 2^(Ea(p) - Ea(n) + Eb) — a power of
+// two, so cand * cs is ldexp(cand * c, e + eb) bit for bit while both stay in the normal range; one ldexp per block and
+// start position instead of one per step: round 3)
 template <int U>
-__device__ __forceinline__ void e4l_bwd_step(double sv, uint32_t hv, double c_cur, double c_nxt, int e_cur, int e_nxt,
-                                             int eb, double* __restrict__ expected_slot, double2* hot, uint32_t n_hot, bool cold_ok, double& acc) {
+__device__ __forceinline__ void e4l_bwd_step(double sv, uint32_t hv, double cs_cur, double cs_nxt,
+                                             double* __restrict__ expected_slot, double2* hot, uint32_t n_hot, bool cold_ok, double& acc) {
     constexpr uint64_t MU = kRowLane0 << U;
     constexpr uint64_t WRAPPED = (uint64_t)((1u << (U + 1)) - 1u) * kRowLane0;  // lanes l <= U: position y0 + 16 + l
     const double best = row_bcast_f64<U>(acc);  // b[q] of the source (end) position
     const double cand = best * sv;              // w * b[q]
-    const double c = sel_f64(WRAPPED, c_nxt, c_cur);                     // a[p] / a[n] of this lane's start position
-    const int e = (int)sel_u32(WRAPPED, (uint32_t)e_nxt, (uint32_t)e_cur);  // Ea(p) - Ea(n)
+    const double cs = sel_f64(WRAPPED, cs_nxt, cs_cur);
     if (sv != 0.0) {  // lattice.rs:305-307
-        const double mg = ldexp(cand * c, e + eb);
+        const double mg = cand * cs;
         if (hv < n_hot)
             atomicAdd(&hot[hv].x, mg);  // ds_add_f64
         else if (cold_ok)
@@ -597,22 +599,23 @@ __global__ __launch_bounds__(1024) void estep4l_bwd_kernel(Estep4Params P) {
                         far += mine ? contrib : 0.0;
                 }
             } else {
-                e4l_bwd_step<0>(sv[0], hvs[0], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<1>(sv[1], hvs[1], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<2>(sv[2], hvs[2], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<3>(sv[3], hvs[3], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<4>(sv[4], hvs[4], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<5>(sv[5], hvs[5], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<6>(sv[6], hvs[6], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<7>(sv[7], hvs[7], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<8>(sv[8], hvs[8], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<9>(sv[9], hvs[9], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<10>(sv[10], hvs[10], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<11>(sv[11], hvs[11], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<12>(sv[12], hvs[12], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<13>(sv[13], hvs[13], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<14>(sv[14], hvs[14], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
-                e4l_bwd_step<15>(sv[15], hvs[15], c_cur, c_nxt, e_cur, e_nxt, eb, expected_slot, hot, n_hot, cold_ok, acc);
+                const double cs_cur = ldexp(c_cur, e_cur + eb), cs_nxt = ldexp(c_nxt, e_nxt + eb);
+                e4l_bwd_step<0>(sv[0], hvs[0], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<1>(sv[1], hvs[1], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<2>(sv[2], hvs[2], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<3>(sv[3], hvs[3], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<4>(sv[4], hvs[4], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<5>(sv[5], hvs[5], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<6>(sv[6], hvs[6], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<7>(sv[7], hvs[7], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<8>(sv[8], hvs[8], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<9>(sv[9], hvs[9], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<10>(sv[10], hvs[10], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<11>(sv[11], hvs[11], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<12>(sv[12], hvs[12], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<13>(sv[13], hvs[13], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<14>(sv[14], hvs[14], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
+                e4l_bwd_step<15>(sv[15], hvs[15], cs_cur, cs_nxt, expected_slot, hot, n_hot, cold_ok, acc);
             }
             const int e = row_max_exponent(acc);
             if (e > -100000) {
