@@ -2291,7 +2291,11 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     }
     const uint64_t Kmax = pieces ? std::max<uint64_t>(K, pc.n) : K;
     // replicas of the expected-count array (see estep4_bwd_kernel): up to 256, within 512 MiB
-    uint32_t n_rep = 256;
+    // (round 3: 2.  The 256 of round 1 kept a handful of very frequent tokens from serialising every wave's atomics; those
+    // are summed in the blocks' LDS since round 2, and the remaining memory-side adds are faster on a small array:
+    // backward kernel 38.3 ms per GiB with 256 replicas, 36.9 with 4, 36.2 with 2, 35.9 with 1 — profiles/r03/r_*)
+    uint32_t n_rep = 2;
+    if (const char* e = knob("TGX_ESTEP_REPLICAS")) n_rep = (uint32_t)std::min(256, std::max(1, atoi(e)));
     while (n_rep > 1 && (size_t)n_rep * n_rev * 8 > (512ull << 20)) n_rep >>= 1;
     const size_t abytes = (size_t)(N + Kmax + 128) * 8, ebytes = (size_t)(n_rep + 1) * n_rev * 8 + 256, zbytes = (size_t)Kmax * 8 + 256;
     double *d_alpha = nullptr, *d_exp = nullptr, *d_z = nullptr, *d_zarr = nullptr;
