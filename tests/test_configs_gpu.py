@@ -121,3 +121,27 @@ def test_two_models_share_one_resident_corpus_from_two_threads():
             np.testing.assert_array_equal(ids, want[i][0][0])
             np.testing.assert_array_equal(oo, want[i][0][1])
             np.testing.assert_array_equal(freq, want[i][1])
+
+
+def test_default_decisions_by_batch_size_on_the_spec_vocabulary():
+    """The launch decisions of run_encode_kernel (tgx_api.cpp) at the sizes they were measured on, with the committed
+    32 000-entry spec vocabulary and no switches: 64 MiB -> the long-sample kernel takes the long samples; 256 MiB -> both
+    encode kernels at once on CUs of their own; 512 MiB -> encode5_kernel alone on rows = bytes / longest sample.  Ids
+    bit-exact against the oracle at every size (the oracle on all host threads)."""
+    import os
+    from util import assert_same_encoding
+    toks, scores, _ = synth.load_spec_vocab(32000)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    threads = max(8, min(64, os.cpu_count() or 8))
+    for mib, want in ((64, "long"), (256, "corun"), (512, "rows")):
+        flat, offs = synth.make_corpus(mib << 20, "mixed", seed_offset=1000)
+        assert_same_encoding(nat, ora, flat, offs, threads=threads)
+        kt = nat.last_kernel_times()
+        if want == "long":
+            assert "encode6_kernel" in kt and nat.last_encode_long_samples() > 0 and nat.last_encode_corun_cus() == 0
+        elif want == "corun":
+            assert "encode6_kernel" in kt and "encode5_kernel" in kt and nat.last_encode_corun_cus() > 0
+            assert 0 < nat.last_encode_long_samples() < offs.size - 1
+        else:
+            assert "encode6_kernel" not in kt and nat.last_encode_corun_cus() == 0
+            assert nat.last_encode_waves_per_cu() <= 10 and nat.last_encode_hot_values() == nat.score_values()
