@@ -81,6 +81,15 @@ tgx_status tgx_model_create(const uint8_t *bytes, const uint64_t *offs, const do
 #define TGX_MODEL_FOR_ESTEP 1u
 tgx_status tgx_model_create_ex(const uint8_t *bytes, const uint64_t *offs, const double *scores,
                                uint32_t vocab_size, int device, uint32_t flags, tgx_model **out);
+
+/* A model for a SUBSET of `parent`'s vocabulary (keep_ids: ascending ids of the parent's tokens; the new id of a token
+ * is its position in keep_ids) with new scores, on the parent's double-arrays: nothing is rebuilt, the tokens that are
+ * gone lose their terminal marks — a trie with dead branches gives the same matches.  What `prune` needs three times
+ * per iteration (src/prune.rs:36-56: a model per EM sub-iteration and one for the pruning step, each a subset of the one
+ * before).  Same flags as tgx_model_create_ex; the parent stays valid.  TGX_ERR_UNSUPPORTED when the parent's vocabulary
+ * has duplicate tokens (build the model with tgx_model_create_ex then). */
+tgx_status tgx_model_create_derived(const tgx_model *parent, const uint32_t *keep_ids, uint32_t n_keep,
+                                    const double *scores, uint32_t flags, tgx_model **out);
 void tgx_model_destroy(tgx_model *m);
 uint32_t tgx_model_vocab_size(const tgx_model *m);     /* Model::vocab_size, src/model.rs:179 */
 uint32_t tgx_model_max_token_len(const tgx_model *m);

@@ -55,3 +55,56 @@ def test_prune_end_to_end_matches_oracle_loop(dropout):
     moved = sum(1 for a, b in zip(got, want) if a[0] != b[0])
     assert moved <= len(got) // 10  # only near-tie neighbours may swap
     assert len(pruner.timings) >= 2 and all(r["to"] < r["from"] for r in pruner.timings)
+
+
+def test_model_derived_from_its_parent_equals_a_model_built_from_scratch():
+    """tgx_model_create_derived (round 3): a model for a subset of another model's vocabulary with new scores, on the
+    other's double-arrays (tokens that are gone lose their terminal marks, nothing is rebuilt).  Encode ids, token
+    frequencies, expected counts, log Z and the 2-best alternatives equal those of a model built from the subset; a
+    second derivation from the derived model too; a parent with duplicate tokens is refused."""
+    import tokengeex_amd as tgx
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 6000, 16, seed_offset=91, max_len=20000)
+    scores = np.asarray(scores, np.float64)
+    rng = np.random.default_rng(17)
+    parent = tgx.NativeModel(toks, scores, for_estep=True)
+    corpus = tgx.NativeCorpus(flat, offs)
+
+    def subset(n_from, frac):
+        keep = np.sort(np.concatenate([np.arange(256), 256 + rng.choice(n_from - 256, int((n_from - 256) * frac), replace=False)])).astype(np.uint32)
+        return keep
+
+    keep1 = subset(len(toks), 0.6)  # (the single bytes stay: every text remains coverable)
+    toks1 = [toks[i] for i in keep1]
+    sc1 = scores[keep1] - rng.random(keep1.size) * 0.2
+    for for_estep in (True, False):
+        d = parent.derive(keep1, sc1, for_estep=for_estep)
+        f = tgx.NativeModel(toks1, sc1, for_estep=for_estep)
+        assert d.vocab_size == f.vocab_size == keep1.size
+        rd, rf = d.encode_corpus(corpus), f.encode_corpus(corpus)
+        assert np.array_equal(rd.ids(), rf.ids()) and np.array_equal(rd.offsets(), rf.offsets())
+        rd.free(); rf.free()
+        assert np.array_equal(d.count_tokens(corpus), f.count_tokens(corpus))
+        ed, zd = d.estep(corpus, 81920, 0.0, 1)
+        ef, zf = f.estep(corpus, 81920, 0.0, 1)
+        np.testing.assert_allclose(ed, ef, rtol=1e-11, atol=1e-13)
+        assert abs(zd - zf) <= 1e-13 * abs(zf)
+        ed, _ = d.estep(corpus, 81920, 0.1, 7)
+        ef, _ = f.estep(corpus, 81920, 0.1, 7)
+        np.testing.assert_allclose(ed, ef, rtol=1e-11, atol=1e-13)
+        ad, af = d.prune_alternatives(), f.prune_alternatives()
+        assert all(np.array_equal(x, y) for x, y in zip(ad, af))
+        # a subset of the subset, from the derived model
+        keep2 = subset(keep1.size, 0.5)
+        sc2 = sc1[keep2] - 0.1
+        d2 = d.derive(keep2, sc2)
+        f2 = tgx.NativeModel([toks1[i] for i in keep2], sc2)
+        rd, rf = d2.encode_corpus(corpus), f2.encode_corpus(corpus)
+        assert np.array_equal(rd.ids(), rf.ids())
+        rd.free(); rf.free()
+        for mm in (d, f, d2, f2):
+            mm.free()
+    dup = tgx.NativeModel(toks + [toks[300]], np.concatenate([scores, [-3.0]]))
+    with pytest.raises(tgx.TokenGeeXError):
+        dup.derive(np.arange(100, dtype=np.uint32), scores[:100])
+    with pytest.raises(tgx.TokenGeeXError):
+        parent.derive(np.array([5, 3], np.uint32), scores[:2])  # not ascending

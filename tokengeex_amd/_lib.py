@@ -30,6 +30,7 @@ SYMBOLS = {
     "tgx_device_count": (_i, []),
     "tgx_model_create": (_i, [_vp, _vp, _vp, _u32, _i, _pvp]),
     "tgx_model_create_ex": (_i, [_vp, _vp, _vp, _u32, _i, _u32, _pvp]),
+    "tgx_model_create_derived": (_i, [_vp, _vp, _u32, _vp, _u32, _pvp]),
     "tgx_model_destroy": (None, [_vp]),
     "tgx_model_vocab_size": (_u32, [_vp]),
     "tgx_model_max_token_len": (_u32, [_vp]),
@@ -421,6 +422,22 @@ class NativeModel:
         if getattr(self, "_h", None):
             lib.tgx_model_destroy(self._h)
             self._h = None
+
+    def derive(self, keep_ids, scores, for_estep: bool = False) -> "NativeModel":
+        """A model for the subset `keep_ids` (ascending ids of this model's tokens) with new scores, on this model's
+        tables (tgx_model_create_derived): what prune builds per EM sub-iteration, without rebuilding the tries.
+        Raises TokenGeeXError (unsupported) when this vocabulary has duplicate tokens."""
+        keep = np.ascontiguousarray(keep_ids, dtype=np.uint32)
+        sc = np.ascontiguousarray(scores, dtype=np.float64)
+        if sc.shape[0] != keep.shape[0]:
+            raise ValueError("scores and keep_ids differ in length")
+        h = C.c_void_p()
+        check(lib.tgx_model_create_derived(self._h, ptr(keep), keep.shape[0], ptr(sc), 1 if for_estep else 0, C.byref(h)))
+        m = NativeModel.__new__(NativeModel)
+        m._scores = sc
+        m._h = h
+        m.device = self.device
+        return m
 
     @property
     def vocab_size(self) -> int:

@@ -1023,6 +1023,9 @@ static tgx_status ensure_encode_tables(tgx_model* m) {
     return TGX_OK;
 }
 
+static tgx_status finish_model_create(tgx_model* m, const uint8_t* bytes, const uint64_t* offs, const double* scores,
+                                      uint32_t vocab_size, int device, uint32_t flags, tgx_model** out);
+
 tgx_status tgx_model_create(const uint8_t* bytes, const uint64_t* offs, const double* scores,
                             uint32_t vocab_size, int device, tgx_model** out) {
     return tgx_model_create_ex(bytes, offs, scores, vocab_size, device, 0, out);
@@ -1084,6 +1087,12 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
         rev_builder.join();
         m->rev_host_built = true;
     }
+    return finish_model_create(m, bytes, offs, scores, vocab_size, device, flags, out);
+}
+
+// the part of model creation after the host tables exist: checks, device tables, uploads
+static tgx_status finish_model_create(tgx_model* m, const uint8_t* bytes, const uint64_t* offs, const double* scores,
+                                      uint32_t vocab_size, int device, uint32_t flags, tgx_model** out) {
     if (m->flat.max_token_len > TGX_MAX_TOKEN_LEN) {
         uint32_t l = m->flat.max_token_len;
         delete m;
@@ -1151,6 +1160,85 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
 #undef HIP_TRY_M
     *out = m;
     return TGX_OK;
+}
+
+// A model for a SUBSET of another model's vocabulary with new scores, on the other model's double-arrays: the tokens that
+// are gone lose their terminal mark, the others get their new id and score, and nothing is rebuilt — a trie with dead
+// branches gives the same matches.  `prune` makes three models per iteration (two EM sub-iterations and the pruning step,
+// src/prune.rs:36-56), each for a subset of the one before; the double-array builds were two thirds of an iteration at
+// 500 000 entries.  keep_ids: ascending ids of the parent's vocabulary; new id = position in keep_ids.
+// Not for parents with duplicate tokens (only the last duplicate is in the parent's tables): TGX_ERR_UNSUPPORTED, the
+// caller builds the model from scratch.
+tgx_status tgx_model_create_derived(const tgx_model* parent, const uint32_t* keep_ids, uint32_t n_keep, const double* scores,
+                                    uint32_t flags, tgx_model** out) {
+    if (!out) return fail(TGX_ERR_INVALID, "tgx_model_create_derived: out is NULL");
+    *out = nullptr;
+    if (!parent || (n_keep && (!keep_ids || !scores))) return fail(TGX_ERR_INVALID, "tgx_model_create_derived: NULL argument");
+    const uint32_t PV = parent->vocab_size;
+    for (uint32_t i = 0; i < n_keep; i++)
+        if (keep_ids[i] >= PV || (i && keep_ids[i] <= keep_ids[i - 1])) return fail(TGX_ERR_INVALID, "tgx_model_create_derived: keep_ids must ascend within the parent's vocabulary");
+    {   // every non-empty token of the parent must own a terminal slot
+        uint64_t non_empty = 0, terminals = 0;
+        for (uint32_t i = 0; i < PV; i++) non_empty += parent->vocab_offs[i + 1] > parent->vocab_offs[i];
+        for (uint32_t t : parent->flat.tokid) terminals += t != tgx::kNoToken;
+        if (terminals != non_empty) return fail(TGX_ERR_UNSUPPORTED, "tgx_model_create_derived: the parent vocabulary has duplicate tokens");
+    }
+    tgx_model* m = new tgx_model();
+    m->device = parent->device;
+    m->vocab_size = n_keep;
+    std::vector<uint32_t> new_id(PV, tgx::kNoToken);
+    for (uint32_t i = 0; i < n_keep; i++) new_id[keep_ids[i]] = i;
+    // the new vocabulary's bytes (the tail of creation copies them into the model)
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> offs(n_keep + 1, 0);
+    uint32_t longest = 0;
+    for (uint32_t i = 0; i < n_keep; i++) {
+        const uint64_t b = parent->vocab_offs[keep_ids[i]], e = parent->vocab_offs[keep_ids[i] + 1];
+        offs[i + 1] = offs[i] + (e - b);
+        longest = std::max<uint32_t>(longest, (uint32_t)(e - b));
+    }
+    bytes.resize(offs[n_keep]);
+    for (uint32_t i = 0; i < n_keep; i++) {
+        const uint64_t b = parent->vocab_offs[keep_ids[i]], e = parent->vocab_offs[keep_ids[i] + 1];
+        if (e > b) memcpy(bytes.data() + offs[i], parent->vocab_bytes.data() + b, (size_t)(e - b));
+    }
+    auto derive = [&](const tgx::FlatTrie& src, tgx::FlatTrie* dst) {
+        *dst = src;
+        dst->max_token_len = longest;
+        for (size_t t = 0; t < dst->tokid.size(); t++) {
+            const uint32_t old = dst->tokid[t];
+            if (old == tgx::kNoToken) continue;
+            const uint32_t nid = new_id[old];
+            tgx::TrieRec& r = dst->table[t];
+            if (nid == tgx::kNoToken) {
+                dst->tokid[t] = tgx::kNoToken;
+                r.base &= ~tgx::kTerminalBit;
+                r.score_bits = 0;
+            } else {
+                dst->tokid[t] = nid;
+                memcpy(&r.score_bits, &scores[nid], 8);
+            }
+        }
+    };
+    std::thread rev_deriver;
+    const bool want_rev = (flags & TGX_MODEL_FOR_ESTEP) && parent->rev_host_built && n_keep;
+    if (want_rev) rev_deriver = std::thread([&]() { derive(parent->flat_rev, &m->flat_rev); });
+    std::thread hash_early;
+    if (!(flags & TGX_MODEL_FOR_ESTEP) && n_keep && longest <= 32) {
+        bool finite = true;
+        for (uint32_t i = 0; i < n_keep; i++) finite = finite && (scores[i] - scores[i] == 0.0);
+        if (finite) hash_early = std::thread([&]() { tgx::build_tok_hash(bytes.data(), offs.data(), n_keep, &m->tokhash); });
+    }
+    derive(parent->flat, &m->flat);
+    if (hash_early.joinable()) {
+        hash_early.join();
+        m->tokhash_host_built = true;
+    }
+    if (rev_deriver.joinable()) {
+        rev_deriver.join();
+        m->rev_host_built = true;
+    }
+    return finish_model_create(m, bytes.data(), offs.data(), scores, n_keep, parent->device, flags, out);
 }
 
 // tgx_prune_alternatives over the model's own double-array (the prune driver has a model of the same vocabulary

@@ -60,10 +60,19 @@ class ModelVocabularyPruner:
         return tdist.allreduce_vector(expected, self.dist, self.reduce_device)
 
     @staticmethod
-    def _m_step(arrays, expected: np.ndarray):
+    def _m_step(arrays, expected: np.ndarray, with_index: bool = False):
         toks, _, keep = arrays
         idx, scores = _lib.prune_m_step(expected, keep)
-        return toks.take(idx), np.asarray(scores, np.float64), keep[np.asarray(idx, np.int64)]
+        out = (toks.take(idx), np.asarray(scores, np.float64), keep[np.asarray(idx, np.int64)])
+        return (out, np.asarray(idx, np.uint32)) if with_index else out
+
+    def _derived(self, parent: "_lib.NativeModel", idx: np.ndarray, arrays, for_estep: bool) -> "_lib.NativeModel":
+        """The model of a SUBSET of `parent`'s vocabulary (round 3): on the parent's tries where the library can
+        (tgx_model_create_derived: no double-array is rebuilt), from scratch otherwise (duplicate tokens)."""
+        try:
+            return parent.derive(idx, arrays[1], for_estep=for_estep)
+        except _lib.TokenGeeXError:
+            return self._model(arrays, for_estep=for_estep)
 
     @staticmethod
     def run_m_step(vocab: Vocab, expected: np.ndarray) -> Vocab:
@@ -92,20 +101,23 @@ class ModelVocabularyPruner:
         try:
             while len(arrays[0]) > self.vocab_size:
                 rec = {"from": len(arrays[0]), "e_step_s": 0.0, "m_step_s": 0.0}
+                # one double-array build per iteration: the models of the later sub-iterations and of the pruning step
+                # are subsets of the first one's vocabulary and live on its tables (tgx_model_create_derived)
+                model = self._model(arrays, for_estep=True)
                 for sub in range(self.em_subiters):
-                    model = self._model(arrays, for_estep=True)
                     t0 = time.perf_counter()
                     expected = self.run_e_step(model, corpus)
                     t1 = time.perf_counter()
-                    new_arrays = self._m_step(arrays, expected)
+                    new_arrays, idx = self._m_step(arrays, expected, with_index=True)
                     t2 = time.perf_counter()
                     rec["e_step_s"] += t1 - t0
                     rec["m_step_s"] += t2 - t1
                     self.log(f"EM subiter {sub + 1}/{self.em_subiters} vocab_size={len(arrays[0])} "
                              f"alternative_vocab_size={len(new_arrays[0])}")
+                    nxt = self._derived(model, idx, new_arrays, for_estep=sub + 1 < self.em_subiters)
                     model.free()
+                    model = nxt
                     arrays = new_arrays
-                model = self._model(arrays)
                 t0 = time.perf_counter()
                 arrays = self._prune_arrays(arrays, model, corpus)
                 rec["prune_vocab_s"] = time.perf_counter() - t0
