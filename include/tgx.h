@@ -305,6 +305,10 @@ uint64_t tgx_last_encode_long_samples(const tgx_model *m);
 /* pieces the last tgx_estep pass cut its snippets into at positions no token match crosses (the lattice factorises
  * there, so expected counts and log Z of the pieces add up to the snippets': csrc/cuts.hip); 0: snippets uncut. */
 uint64_t tgx_last_estep_pieces(const tgx_model *m);
+/* stretches of text the last tgx_estep pass on estep7_kernel (one walk per position: every trip of 16 .. 64 positions a
+ * lattice of its own between two positions no match crosses) could not close within a trip and handed to its redo
+ * pass (csrc/estep7.hip); 0: none. */
+uint64_t tgx_last_estep_redo(const tgx_model *m);
 /* CUs the long-sample kernel had to itself while encode5_kernel ran on the others in the last encode pass
  * (batches of a few hundred MB whose longest samples bound either kernel alone); 0: the kernels ran one after the other. */
 uint32_t tgx_last_encode_corun_cus(const tgx_model *m);

@@ -67,7 +67,7 @@ def test_config3_prune_passes_at_500k_vocab():
     assert abs(gz - wz) <= 1e-12 * abs(wz) + 1e-9
     mass = float(np.dot(got, np.array([len(t) for t in toks], np.float64)))
     assert abs(mass - sf.size) < 1e-6 * sf.size       # every byte covered with total mass 1
-    assert any(name.startswith("estep4l") for name in nat.last_kernel_times())
+    assert "estep7_kernel" in nat.last_kernel_times()   # round 4: 32-bit match entries for more than 65 535 tokens
 
 
 def test_bench_starts_its_own_ranks():

@@ -82,7 +82,7 @@ def test_estep_realistic_corpus():
     # every byte of the corpus is covered with total mass 1
     mass = float(sum(got[i] * len(toks[i]) for i in range(len(toks))))
     assert abs(mass - flat.size) < 1e-6 * flat.size
-    assert any(k.startswith("estep") for k in nat.last_kernel_times())
+    assert "estep7_kernel" in nat.last_kernel_times()   # round 4: the default for tokens of at most 16 bytes
 
 
 def test_estep_snippets_long_samples_and_token_lengths():
@@ -260,7 +260,7 @@ def test_estep_falls_back_to_log_domain_when_a_position_has_no_incoming_token():
     toks = [bytes([c]) for c in b"abcdefgh"] + [b"ab", b"abc", b"cd", b"efg", b"gh", b"hh"]
     scores = -np.linspace(1.0, 4.0, len(toks))
     nat, ora = _pair(toks, scores)
-    for texts, bwd in (([b"abcdefgh" * 40, b"hhgfedcba" * 13, b"a"], "estep4l_bwd_kernel"),
+    for texts, bwd in (([b"abcdefgh" * 40, b"hhgfedcba" * 13, b"a"], "estep7_kernel"),
                        ([b"abcdefgh" * 40, b"abcXdefgh" * 9, b"a"], "estep4_bwd_kernel")):
         flat, offs = tgx.pack(texts)
         got, gz = nat.estep(tgx.NativeCorpus(flat, offs), 81920, 0.0, 0)
@@ -272,7 +272,7 @@ def test_estep_falls_back_to_log_domain_when_a_position_has_no_incoming_token():
         assert abs(gz - wz) <= 1e-12 * abs(wz)
 
 
-def test_estep_error_budget_against_extended_precision():
+def test_estep_error_budget_against_extended_precision(monkeypatch):
     """Where the E-step tolerance comes from: one 64 KiB snippet evaluated in 80-bit extended precision
     (util.estep_longdouble), by the oracle (the reference's f64 log-domain arithmetic) and by the kernels.
     The linear-domain kernels must sit within 1e-11 of the extended-precision values; the oracle's own
@@ -287,17 +287,21 @@ def test_estep_error_budget_against_extended_precision():
     truth, zt = estep_longdouble(ora, text)
     want, zo = ora.marginal(text)
     f, o = tgx.pack([text])
-    got, zg = nat.estep(tgx.NativeCorpus(f, o))
-    assert "estep4l_bwd_kernel" in nat.last_kernel_times()
     big = np.abs(truth) > 1e-9
 
     def err(x):
         return float((np.abs(x - truth)[big] / np.abs(truth)[big]).max())
-    e_gpu, e_ora = err(got), err(want)
-    assert e_gpu < 1e-11, e_gpu
+    e_ora = err(want)
     assert e_ora < rtol_for(len(text)), e_ora
-    assert e_gpu * 50 < e_ora                      # the deviation between the two is the oracle's rounding
-    assert abs(zg - zt) <= 1e-13 * abs(zt) and abs(zo - zt) <= 1e-13 * abs(zt)
+    for mode, kernel in ((None, "estep7_kernel"), ("chain", "estep4l_bwd_kernel")):
+        if mode:
+            monkeypatch.setenv("TGX_ESTEP", mode)
+        got, zg = nat.estep(tgx.NativeCorpus(f, o))
+        assert kernel in nat.last_kernel_times()
+        e_gpu = err(got)
+        assert e_gpu < 1e-11, (kernel, e_gpu)
+        assert e_gpu * 50 < e_ora                      # the deviation between the two is the oracle's rounding
+        assert abs(zg - zt) <= 1e-13 * abs(zt) and abs(zo - zt) <= 1e-13 * abs(zt)
 
 
 @pytest.mark.parametrize("eppl", ["1", "2", "4"])
@@ -305,6 +309,7 @@ def test_estep_every_positions_per_lane_variant(monkeypatch, eppl):
     """The linear-domain kernels exist for 1, 2 and 4 positions per lane (the host normally picks by the shape of
     the pass): each against the oracle, with snippets that end on and off block boundaries and dropout."""
     monkeypatch.setenv("TGX_EPPL", eppl)
+    monkeypatch.setenv("TGX_ESTEP", "chain")   # the chained forward / backward kernels (rounds 1 - 3)
     flat, offs, toks, scores = corpus_and_vocab(512 << 10, "mixed", 3000, 16, seed_offset=21, max_len=20000)
     nat, ora = _pair(toks, scores)
     _check_estep(nat, ora, flat, offs, snippet_len=4096, dropout=0.1, seed=11)
@@ -410,6 +415,7 @@ def test_estep_forward_sweep_on_ranked_records(monkeypatch, eppl, hot):
     read from L2) against the oracle and against estep4l_fwd_kernel (TGX_ESTEP_FWD=rows4): same matches, same weights,
     same steps, so the two agree to the rounding of the backward kernel's unordered sums; every positions-per-lane
     build, tables smaller than the vocabulary's values (COLD builds), dropout, pieces, distinct scores."""
+    monkeypatch.setenv("TGX_ESTEP", "chain")   # the chained forward / backward kernels (rounds 1 - 3)
     if eppl:
         monkeypatch.setenv("TGX_EPPL", eppl)
     if hot:
@@ -437,3 +443,71 @@ def test_estep_forward_sweep_on_ranked_records(monkeypatch, eppl, hot):
         np.testing.assert_allclose(got, old, rtol=1e-11, atol=1e-13)
         assert abs(gz - oz) <= 1e-13 * abs(oz)
         monkeypatch.delenv("TGX_ESTEP_FWD")
+
+
+# ---- round 4: one walk per position, every trip a lattice of its own (csrc/estep7.hip) -------------------------------
+
+@pytest.mark.parametrize("eppl,hot,waves", [(None, None, None), ("1", None, None), ("2", None, "12"), ("3", "300", None), ("4", "0", "6"), ("4", None, "3")])
+def test_estep7_every_build_against_the_oracle_and_the_chained_kernels(monkeypatch, eppl, hot, waves):
+    """estep7_kernel: every positions-per-lane build, tables smaller than the vocabulary (COLD builds: weights from L2,
+    expected counts to HBM), dropout, forced pieces, every token its own score — against the oracle and against the
+    chained kernels of rounds 1 - 3 (both sum the same products, in different orders: 1e-11)."""
+    if eppl:
+        monkeypatch.setenv("TGX_EPPL", eppl)
+    if hot:
+        monkeypatch.setenv("TGX_E7_HOT", hot)
+    if waves:
+        monkeypatch.setenv("TGX_E7_WAVES", waves)
+    flat, offs, toks, scores = corpus_and_vocab(2 << 20, "mixed", 8000, 16, seed_offset=81, max_len=30000)
+    rng = np.random.default_rng(31)
+    for sc in (scores, np.asarray(scores) + rng.uniform(-0.3, 0.3, len(toks))):
+        nat, ora = _pair(toks, sc)
+        got, gz = _check_estep(nat, ora, flat, offs)
+        assert "estep7_kernel" in nat.last_kernel_times()
+        if eppl in ("1", "2"):   # short trips find no cut now and then: the redo kernel takes those stretches
+            assert nat.last_estep_redo() > 0 and "estep7_redo_kernel" in nat.last_kernel_times()
+        _check_estep(nat, ora, flat, offs, dropout=0.2, seed=5)
+        assert "estep7_kernel" in nat.last_kernel_times()
+        monkeypatch.setenv("TGX_ESTEP_PIECES", "1")
+        monkeypatch.setenv("TGX_ESTEP_WINDOW", "512")
+        _check_estep(nat, ora, flat, offs)
+        assert "estep7_kernel" in nat.last_kernel_times() and nat.last_estep_pieces() > offs.size
+        monkeypatch.delenv("TGX_ESTEP_PIECES")
+        monkeypatch.delenv("TGX_ESTEP_WINDOW")
+        monkeypatch.setenv("TGX_ESTEP", "chain")
+        corpus = tgx.NativeCorpus(flat, offs)
+        old, oz = nat.estep(corpus)
+        assert "estep4l_bwd_kernel" in nat.last_kernel_times() and "estep7_kernel" not in nat.last_kernel_times()
+        np.testing.assert_allclose(got, old, rtol=1e-11, atol=1e-13)
+        assert abs(gz - oz) <= 1e-13 * abs(oz)
+        monkeypatch.delenv("TGX_ESTEP")
+
+
+def test_estep7_small_cases_snippet_ends_and_texts_without_cuts():
+    """Trips that end on and off group boundaries, pieces of exactly 16 / 48 / 64 / 65 positions, snippets cut through
+    tokens, and runs of one byte under the tokens a, aa, aaaa (no position is a cut: everything goes through the redo
+    kernel, whose trips are spilled to scratch) with and without dropout."""
+    toks = [b"a", b"aa", b"aaaa", b"b", b"ab", b"c", b"abc"]
+    scores = [-1.0, -1.6, -2.5, -2.0, -2.2, -3.0, -2.4]
+    nat, ora = _pair(toks, scores)
+    texts = [b"a" * 5000, b"a" * 300 + b"b" + b"a" * 2000, (b"a" * 999 + b"b") * 8, b"ab" * 700, b"", b"a", b"b" * 15, b"b" * 16, b"b" * 17,
+             b"cb" * 24, b"c" * 63, b"c" * 64, b"c" * 65, b"abc" * 21 + b"a", b"b" * 47 + b"a" * 40 + b"c" * 30]
+    flat, offs = tgx.pack(texts)
+    _check_estep(nat, ora, flat, offs, rtol=1e-9)
+    assert "estep7_kernel" in nat.last_kernel_times() and "estep7_redo_kernel" in nat.last_kernel_times()
+    assert nat.last_estep_redo() >= 3
+    _check_estep(nat, ora, flat, offs, snippet_len=1000, rtol=1e-9)
+    _check_estep(nat, ora, flat, offs, snippet_len=48, rtol=1e-9)
+    _check_estep(nat, ora, flat, offs, dropout=0.3, seed=3, rtol=1e-9)
+    _check_estep(nat, ora, flat, offs, snippet_len=100, dropout=0.5, seed=9, rtol=1e-9)
+
+
+def test_estep7_with_more_than_65535_tokens():
+    """32-bit match entries: the committed 500 000-entry vocabulary of BASELINE.json configs[3]."""
+    from util import load_vocab_500k
+    toks, scores = load_vocab_500k()
+    nat, ora = _pair(toks, scores)
+    flat, offs = synth.make_corpus(2 << 20, "mixed", seed_offset=77)
+    _check_estep(nat, ora, flat, offs)
+    assert "estep7_kernel" in nat.last_kernel_times()
+    _check_estep(nat, ora, flat, offs, dropout=0.1, seed=2)

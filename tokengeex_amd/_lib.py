@@ -92,6 +92,7 @@ SYMBOLS = {
     "tgx_last_encode_hot_values": (_u32, [_vp]),
     "tgx_last_encode_long_samples": (_u64, [_vp]),
     "tgx_last_estep_pieces": (_u64, [_vp]),
+    "tgx_last_estep_redo": (_u64, [_vp]),
     "tgx_last_encode_corun_cus": (_u32, [_vp]),
 }
 
@@ -568,6 +569,9 @@ class NativeModel:
 
     def last_estep_pieces(self) -> int:
         return lib.tgx_last_estep_pieces(self._h)
+
+    def last_estep_redo(self) -> int:
+        return lib.tgx_last_estep_redo(self._h)
 
     def last_encode_corun_cus(self) -> int:
         return lib.tgx_last_encode_corun_cus(self._h)

@@ -192,4 +192,26 @@ hipError_t launch_piece_z_check(const double* zarr, const uint32_t* psnip, uint6
     return hipGetLastError();
 }
 
+// the two halves of launch_piece_z_check on their own (estep7.hip: the kernel sums z per snippet itself; the stretches
+// its redo list hands to the chained kernels are listed by `order` — every second entry of the pseudo-snippet list)
+__global__ __launch_bounds__(256) void piece_z_order_kernel(const double* __restrict__ zarr, const uint32_t* __restrict__ psnip,
+                                                            const uint32_t* __restrict__ order, uint64_t n_order, double* __restrict__ zsnip) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_order; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = order[j];
+        atomicAdd(&zsnip[psnip[k]], zarr[k]);
+    }
+}
+hipError_t launch_piece_z_add(const double* zarr, const uint32_t* psnip, const uint32_t* order, uint64_t n_order, double* zsnip, hipStream_t stream) {
+    if (n_order == 0) return hipSuccess;
+    const uint32_t b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_order + 255) / 256, 2048));
+    hipLaunchKernelGGL(piece_z_order_kernel, dim3(b), dim3(256), 0, stream, zarr, psnip, order, n_order, zsnip);
+    return hipGetLastError();
+}
+hipError_t launch_snip_z_check(const double* zsnip, uint64_t n_snips, unsigned long long* err_snip, hipStream_t stream) {
+    if (n_snips == 0) return hipSuccess;
+    const uint32_t b = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((n_snips + 255) / 256, 2048));
+    hipLaunchKernelGGL(snip_z_check_kernel, dim3(b), dim3(256), 0, stream, zsnip, n_snips, err_snip);
+    return hipGetLastError();
+}
+
 }  // namespace tgx

@@ -32,30 +32,6 @@
 
 namespace tgx {
 
-// LDS accesses by byte offset (32-bit LDS pointers): no 64-bit flat address arithmetic, no "+ base of the dynamic
-// LDS" per access — the kernel folds that base (0 when a kernel has no static LDS) into its per-lane constants once
-template <class T>
-__device__ __forceinline__ T lds_ld(uint32_t off) { return *(const __attribute__((address_space(3))) T*)(uintptr_t)off; }
-template <class T>
-__device__ __forceinline__ void lds_st(uint32_t off, T v) { *(__attribute__((address_space(3))) T*)(uintptr_t)off = v; }
-
-// The trie records and the value table are read through buffer resources: `buffer_load_dwordx2 v, voffset, rsrc, 0
-// offen` takes a 32-bit byte offset per lane (a global_load of base + offset needs a 64-bit add per lane, or a form
-// the compiler only picks for scaled indices), and an offset beyond the table reads zeros instead of faulting.
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);  // raw buffer, 32-bit data format
-}
-__device__ __forceinline__ uint2 buf_ld8(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
-    return make_uint2(v.x, v.y);
-}
-__device__ __forceinline__ double buf_ld_f64(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
-    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
-    return __hiloint2double((int)v.y, (int)v.x);
-}
-
 // match-index buffer of one 16-position group: four sample rows of 16 columns x 16 start positions x 2 bytes
 // = 2 KiB per wave and group, 512-byte aligned.  Entry (start u, len) of row r: r * 512 + ((len - 1 + u) & 15) * 32
 // + u * 2 — lane l of the row, which at step u accumulates end position u + len with len - 1 = (l - u - 1) & 15,

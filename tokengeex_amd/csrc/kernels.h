@@ -159,6 +159,81 @@ hipError_t piece_sort(void* temp, size_t temp_bytes, const uint32_t* len_in, uin
 hipError_t launch_piece_z_check(const double* zarr, const uint32_t* psnip, uint64_t n_pieces, double* zsnip, uint64_t n_snips,
                                 unsigned long long* err_snip, hipStream_t stream);
 
+// estep7_kernel (estep7.hip): the E-step with one walk per position — every trip of a row is a lattice of its own
+// between two positions no match crosses; match entries are token ranks (trie_build.h: Trie8T)
+// (what a row needs once per piece or less often lives behind a pointer, in device memory: as kernel arguments these
+// twenty scalar-register pairs pushed the buffer resources of the walk out to spilled lanes — 4 v_readlane and their
+// hazard nops per walk level)
+struct Estep7Work {
+    const uint64_t* soffs;          // u64[K+1] pieces (or snippets): k = text[soffs[k] .. soffs[k+1])
+    const uint32_t* order;          // u32[K]
+    uint64_t n_snips;
+    const uint32_t* snip_sample;    // u32[K], u64[K]: sample and offset in the sample (dropout hash only)
+    const uint64_t* snip_base;
+    const uint32_t* snip_of;        // u32[K] snippet a piece belongs to (z is summed per snippet); null: k itself
+    double* zsnip;                  // f64[snippets] log Z per snippet (sum of its pieces' trips)
+    double* logz_sum;
+    unsigned long long* range_flag; // 1: a position nothing reaches or a value out of range; 4: redo list full
+    unsigned long long* queue;
+    unsigned long long* redo_count; // stretches the kernel could not do (no cut within a trip) ...
+    uint64_t* redo_offs;            // ... u64[2 cap]: [2 i], [2 i + 1] = begin and end of stretch i
+    uint32_t* redo_sample;          // u32[2 cap], u64[2 cap], u32[2 cap]: sample, offset in the sample, snippet (entries 2 i and 2 i + 1 alike)
+    uint64_t* redo_base;
+    uint32_t* redo_snip;
+    uint64_t redo_cap;
+};
+struct Estep7Params {
+    const uint8_t* text;
+    const Estep7Work* work;         // device memory (the launcher uploads `host_work` there)
+    Estep7Work host_work;           // filled by the caller; not read by the kernel
+    const void* trie8t;             // Trie8TRec[n_slots]
+    uint32_t n_slots;
+    uint32_t root_base;
+    const double* wtab;             // f64[n_tok + 1]: [0] = 0, [r] = exp(score of the token of rank r)
+    uint32_t n_tok;                 // tokens that can match (ranks 1 .. n_tok)
+    uint32_t n_hot;                 // ranks 1 .. n_hot have {sum, w} in the block's LDS
+    double* expected;               // f64[n_tok + 1] expected counts by rank
+    double dropout;
+    uint64_t seed;
+    uint32_t claim_chunk;
+    uint32_t root_off, zero_off, idx_off;  // LDS layout (set by the launcher)
+    uint32_t flags;                 // timing experiments only (TGX_FLAGS with TGX_DEBUG=1): results are WRONG when set
+    unsigned long long* stamps;     // diagnostic runs only (TGX_STAMPS=7 with TGX_DEBUG=1): 8 u64 per wave
+};
+struct Estep7RedoParams {
+    const uint8_t* text;
+    const uint64_t* redo_offs;      // as written by estep7_kernel
+    const uint32_t* redo_sample;
+    const uint64_t* redo_base;
+    const uint32_t* redo_snip;
+    uint64_t n_redo;
+    const uint64_t* tbase;          // u64[n_redo]: trips of the stretches before stretch i (the scratch layout)
+    const void* trie8t;
+    uint32_t n_slots;
+    uint32_t root_base;
+    const double* wtab;
+    uint32_t n_tok, n_hot;
+    double* expected;
+    double* zsnip;
+    double* logz_sum;
+    unsigned long long* range_flag;
+    unsigned long long* queue;
+    double* alpha;                  // f64[16 trips]
+    int32_t* aexp;                  // i32[trips]
+    unsigned char* mscratch;        // row images of the trips' match entries: trips x 512 (1024) bytes
+    double dropout;
+    uint64_t seed;
+    uint32_t root_off, zero_off, idx_off;  // LDS layout (set by the launcher)
+};
+uint32_t estep7_redo_max_hot(bool wide);
+hipError_t launch_estep7_redo(Estep7RedoParams p, bool wide, uint32_t num_cus, hipStream_t stream);
+uint32_t estep7_lds_layout(uint32_t n_hot, bool wide, int waves, int ppl, uint32_t* root_off, uint32_t* zero_off, uint32_t* idx_off);
+uint32_t estep7_max_hot(bool wide, int waves, int ppl, uint32_t budget);
+hipError_t estep7_waves_per_simd(bool dropout, bool cold, bool wide, int ppl, int* out);
+hipError_t launch_estep7(Estep7Params p, bool wide, int ppl, int waves, uint32_t blocks, hipStream_t stream);
+hipError_t launch_snip_z_check(const double* zsnip, uint64_t n_snips, unsigned long long* err_snip, hipStream_t stream);
+hipError_t launch_piece_z_add(const double* zarr, const uint32_t* psnip, const uint32_t* order, uint64_t n_order, double* zsnip, hipStream_t stream);
+
 hipError_t estep4_prepare();
 hipError_t launch_estep4_fwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);
 hipError_t launch_estep4_bwd(const Estep4Params& p, uint32_t num_cus, hipStream_t stream);

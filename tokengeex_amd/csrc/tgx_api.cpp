@@ -217,6 +217,13 @@ struct tgx_model {
     bool have_wvalues = false;         // d_trie8 / d_wvalues are there for estep5_fwd_kernel
     double* d_wvalues = nullptr;       // f64[n_values + 1]: [0] = 0, [r] = exp(score value of rank r)
     bool tokhash_host_built = false;   // m->tokhash was built beside the forward trie at creation
+    // estep7_kernel: token-ranked 8-byte records, w by rank (trie_build.h: Trie8T), built at the first E-step
+    void* d_trie8t = nullptr;
+    double* d_wtab = nullptr;          // f64[n_tok7 + 1]
+    std::vector<uint32_t> id_of_rank;  // [r] = vocabulary id of the token of rank r (1 .. n_tok7)
+    uint32_t n_tok7 = 0, root_base7 = 0;
+    bool trie8t_tried = false, have_trie8t = false;
+    uint64_t last_estep_redo = 0;      // stretches the last fused E-step left to the chained kernels
     int estep_blocks_per_cu = 0;
     KernelTime timed[kMaxTimed] = {};
     int n_timed = 0;
@@ -1268,6 +1275,8 @@ void tgx_model_destroy(tgx_model* m) {
     if (m->d_ctrl) (void)hipFree(m->d_ctrl);
     if (m->h_ctrl) (void)hipHostFree(m->h_ctrl);
     if (m->d_wvalues) (void)hipFree(m->d_wvalues);
+    if (m->d_trie8t) (void)hipFree(m->d_trie8t);
+    if (m->d_wtab) (void)hipFree(m->d_wtab);
     if (m->stream2) (void)hipStreamDestroy(m->stream2);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -2169,19 +2178,13 @@ static tgx_status ensure_estep_trie8(tgx_model* m) {
     return TGX_OK;
 }
 
-// E-step on the four-snippets-per-wave kernels (estep4.hip).  Caller holds m->mu and has
-// built the reversed trie.
-// `fallback` (vocabularies with tokens of 17..32 bytes only): set when the linear-domain kernels cannot do the
-// pass (a position without an incoming token, the f64 range left, an overflow list full) — there are no log-domain
-// rows4 kernels for such vocabularies, the caller goes on to the generic kernel; `expected` is untouched then.
-static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout,
-                              uint64_t seed, double* expected, double* logz_sum, bool* fallback) {
-    const bool long_tokens = m->lm > 16;
-    if (fallback) *fallback = false;
-    const uint64_t S = c->n_samples, N = c->n_bytes;
-    // the work list: every sample cut at multiples of snippet_len (src/prune.rs:83), kept with the corpus
+// The E-step's work list of a corpus: every sample cut at multiples of snippet_len (src/prune.rs:83), longest snippet
+// first, with its device copies; kept with the corpus (caller holds both locks).
+static tgx_status ensure_estep_work(tgx_model* m, tgx_corpus* c, uint64_t snippet_len) {
     tgx_corpus::EstepWork& es = c->es;
-    if (es.snippet_len != snippet_len) {
+    if (es.snippet_len == snippet_len) return TGX_OK;
+    const uint64_t S = c->n_samples, N = c->n_bytes;
+    {
         pool_free(c->device, es.d_soffs, es.obytes);
         pool_free(c->device, es.d_sbase, es.obytes);
         pool_free(c->device, es.d_order, es.ordbytes);
@@ -2231,6 +2234,439 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             return fail(TGX_ERR_DEVICE, "E-step work list upload failed");
         es.snippet_len = snippet_len;
     }
+    return TGX_OK;
+}
+
+// ---- pieces (cuts.hip): long snippets cut where no token match crosses — the lattice factorises there
+struct EstepPieces {
+    uint64_t n = 0, longest = 0, cap = 0;
+    uint64_t *d_bound = nullptr, *d_pos = nullptr, *d_offs = nullptr, *d_base = nullptr;
+    uint32_t *d_flag = nullptr, *d_sample = nullptr, *d_snip = nullptr, *d_len = nullptr, *d_idx = nullptr, *d_len2 = nullptr, *d_order = nullptr;
+    void *d_scan = nullptr, *d_sort = nullptr;
+    double* d_zsnip = nullptr;
+    size_t scan_bytes = 0, sort_bytes = 0, zsnip_bytes = 0;
+};
+static void estep_pieces_free(tgx_model* m, EstepPieces& pc) {
+    pool_free(m->device, pc.d_bound, pc.cap * 8 + 256);
+    pool_free(m->device, pc.d_pos, (pc.cap + 1) * 8 + 256);
+    pool_free(m->device, pc.d_offs, (pc.cap + 1) * 8 + 256);
+    pool_free(m->device, pc.d_base, pc.cap * 8 + 256);
+    pool_free(m->device, pc.d_flag, (pc.cap + 1) * 4 + 256);
+    pool_free(m->device, pc.d_sample, pc.cap * 4 + 256);
+    pool_free(m->device, pc.d_snip, pc.cap * 4 + 256);
+    pool_free(m->device, pc.d_len, pc.cap * 4 + 256);
+    pool_free(m->device, pc.d_idx, pc.cap * 4 + 256);
+    pool_free(m->device, pc.d_len2, pc.cap * 4 + 256);
+    pool_free(m->device, pc.d_order, pc.cap * 4 + 256);
+    pool_free(m->device, pc.d_scan, pc.scan_bytes);
+    pool_free(m->device, pc.d_sort, pc.sort_bytes);
+    pool_free(m->device, pc.d_zsnip, pc.zsnip_bytes);
+    pc = EstepPieces{};
+}
+// the windows of the corpus's snippets (one boundary is sought per window), kept with the work list
+static tgx_status ensure_estep_windows(tgx_model* m, tgx_corpus* c, uint32_t window) {
+    tgx_corpus::EstepWork& es = c->es;
+    if (es.window == window && es.d_win_snip) return TGX_OK;
+    const uint64_t K = es.soffs.size() - 1, N = c->n_bytes;
+    pool_free(c->device, es.d_win_snip, es.winbytes);
+    pool_free(c->device, es.d_win_k, es.winbytes);
+    es.d_win_snip = es.d_win_k = nullptr;
+    es.window = 0;
+    std::vector<uint32_t> ws, wk;
+    ws.reserve(K + N / window + 2);
+    wk.reserve(K + N / window + 2);
+    for (uint64_t k = 0; k < K; k++) {
+        const uint64_t len = es.soffs[k + 1] - es.soffs[k];
+        for (uint64_t j = 0; j * window < len; j++) {
+            ws.push_back((uint32_t)k);
+            wk.push_back((uint32_t)j);
+        }
+    }
+    es.n_windows = ws.size();
+    es.winbytes = es.n_windows * 4 + 256;
+    if (pool_alloc(c->device, es.winbytes, (void**)&es.d_win_snip) != hipSuccess ||
+        pool_alloc(c->device, es.winbytes, (void**)&es.d_win_k) != hipSuccess)
+        return fail(TGX_ERR_DEVICE, "out of device memory (E-step windows)");
+    if (hipMemcpyAsync(es.d_win_snip, ws.data(), es.n_windows * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+        hipMemcpyAsync(es.d_win_k, wk.data(), es.n_windows * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return fail(TGX_ERR_DEVICE, "E-step window list upload failed");
+    es.window = window;
+    return TGX_OK;
+}
+// cut_windows_kernel, scan, scatter, lengths, longest-first order: the piece list of this pass (dropout decides the
+// matches, so the list is per pass).  trie16: a 16-byte-record table of the forward tokens (scores or weights alike).
+static tgx_status estep_pieces_build(tgx_model* m, tgx_corpus* c, const void* trie16, double dropout, uint64_t seed, EstepPieces* out) {
+    tgx_corpus::EstepWork& es = c->es;
+    EstepPieces& pc = *out;
+    const uint64_t K = es.soffs.size() - 1, N = c->n_bytes;
+    const uint64_t W = es.n_windows;
+    pc.cap = W;
+    pc.zsnip_bytes = (size_t)K * 8 + 256;
+    auto bad = [&](const char* what) {
+        (void)hipStreamSynchronize(m->stream);
+        estep_pieces_free(m, pc);
+        return fail(TGX_ERR_DEVICE, "E-step pieces: %s", what);
+    };
+    if (tgx::scan_temp_bytes(W, &pc.scan_bytes) != hipSuccess || tgx::piece_sort_temp_bytes(W, &pc.sort_bytes) != hipSuccess)
+        return bad("scratch sizes");
+    if (pool_alloc(m->device, W * 8 + 256, (void**)&pc.d_bound) != hipSuccess ||
+        pool_alloc(m->device, (W + 1) * 8 + 256, (void**)&pc.d_pos) != hipSuccess ||
+        pool_alloc(m->device, (W + 1) * 8 + 256, (void**)&pc.d_offs) != hipSuccess ||
+        pool_alloc(m->device, W * 8 + 256, (void**)&pc.d_base) != hipSuccess ||
+        pool_alloc(m->device, (W + 1) * 4 + 256, (void**)&pc.d_flag) != hipSuccess ||
+        pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_sample) != hipSuccess ||
+        pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_snip) != hipSuccess ||
+        pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_len) != hipSuccess ||
+        pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_idx) != hipSuccess ||
+        pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_len2) != hipSuccess ||
+        pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_order) != hipSuccess ||
+        (pc.scan_bytes && pool_alloc(m->device, pc.scan_bytes, &pc.d_scan) != hipSuccess) ||
+        (pc.sort_bytes && pool_alloc(m->device, pc.sort_bytes, &pc.d_sort) != hipSuccess) ||
+        pool_alloc(m->device, pc.zsnip_bytes, (void**)&pc.d_zsnip) != hipSuccess)
+        return bad("out of device memory");
+    tgx::CutParams q{};
+    q.text = c->d_text;
+    q.soffs = es.d_soffs;
+    q.snip_sample = es.d_ssample;
+    q.snip_base = es.d_sbase;
+    q.win_snip = es.d_win_snip;
+    q.win_k = es.d_win_k;
+    q.n_windows = W;
+    q.window = es.window;
+    q.trie = trie16;
+    q.root = m->flat.table[0].base & ~tgx::kTerminalBit;
+    q.lmx = m->lm > 16 ? 32u : 16u;
+    q.dropout = dropout;
+    q.seed = seed;
+    q.bound = pc.d_bound;
+    q.flag = pc.d_flag;
+    unsigned long long* const d_longest = m->d_ctrl + 6;
+    time_begin(m, "cut_windows_kernel");
+    if (tgx::launch_cut_windows(q, m->stream) != hipSuccess) return bad("cut kernel launch failed");
+    time_end(m);
+    time_begin(m, "piece_list");
+    if (hipMemsetAsync(d_longest, 0, 8, m->stream) != hipSuccess || hipMemsetAsync(pc.d_zsnip, 0, pc.zsnip_bytes, m->stream) != hipSuccess ||
+        tgx::launch_scan(pc.d_flag, pc.d_pos, W, pc.d_scan, pc.scan_bytes, m->stream) != hipSuccess ||
+        tgx::launch_cut_scatter(q, pc.d_pos, N, pc.d_offs, pc.d_sample, pc.d_base, pc.d_snip, m->stream) != hipSuccess ||
+        tgx::launch_piece_len(pc.d_offs, pc.d_pos + W, pc.d_len, pc.d_idx, d_longest, W, m->stream) != hipSuccess ||
+        tgx::piece_sort(pc.d_sort, pc.sort_bytes, pc.d_len, pc.d_len2, pc.d_idx, pc.d_order, W, m->stream) != hipSuccess)
+        return bad("piece list kernels failed");
+    time_end(m);
+    unsigned long long h_n = 0, h_longest = 0;
+    if (hipMemcpyAsync(&h_n, pc.d_pos + W, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(&h_longest, d_longest, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return bad("piece list read-back failed");
+    if (h_n < K || h_n > W) return bad("inconsistent piece count");
+    pc.n = h_n;
+    pc.longest = h_longest;
+    return TGX_OK;
+}
+
+// The token-ranked records and weights of estep7_kernel (estep7.hip): vocabularies with finite scores within +-300
+// (w = exp(score) and its products must stay inside the f64 range, as for the other linear-domain kernels) and tokens of
+// at most 16 bytes.  ~40 ns of host time per token.
+static tgx_status ensure_estep_trie8t(tgx_model* m) {
+    if (m->trie8t_tried) return TGX_OK;
+    m->trie8t_tried = true;
+    if (!(m->lm <= 16 && m->scores_finite && m->vocab_size && m->flat.table.size() <= tgx::kTrie8TMaxSlots)) return TGX_OK;
+    for (uint32_t i = 0; i < m->vocab_size; i++)
+        if (!(m->vocab_scores[i] >= -300.0 && m->vocab_scores[i] <= 300.0)) return TGX_OK;
+    tgx::Trie8T t8;
+    tgx::build_trie8t(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), &t8);
+    if (!t8.ok || t8.n_tok == 0) return TGX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    const size_t ns = t8.rec.size(), nw = t8.w.size();
+    if (!m->d_trie8t) HIP_TRY(hipMalloc(&m->d_trie8t, ns * sizeof(tgx::Trie8TRec)));
+    if (!m->d_wtab) HIP_TRY(hipMalloc((void**)&m->d_wtab, nw * 8));
+    HIP_TRY(hipMemcpy(m->d_trie8t, t8.rec.data(), ns * sizeof(tgx::Trie8TRec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_wtab, t8.w.data(), nw * 8, hipMemcpyHostToDevice));
+    m->id_of_rank = std::move(t8.id_of_rank);
+    m->n_tok7 = t8.n_tok;
+    m->root_base7 = t8.root_base;
+    m->have_trie8t = true;
+    return TGX_OK;
+}
+
+// E-step on estep7_kernel (estep7.hip): one walk per position, every trip of a row a lattice of its own.  Caller holds
+// both locks.  `fallback`: the chained kernels must do the pass (no records for this vocabulary, a position nothing
+// reaches, a value out of range); `expected` is untouched then.
+static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout, uint64_t seed, double* expected,
+                              double* logz_sum, bool* fallback) {
+    *fallback = false;
+    {
+        const tgx_status tst = ensure_estep_trie8t(m);
+        if (tst != TGX_OK) return tst;
+        if (!m->have_trie8t) {
+            *fallback = true;
+            return TGX_OK;
+        }
+        const tgx_status wst = ensure_estep_work(m, c, snippet_len);
+        if (wst != TGX_OK) return wst;
+    }
+    tgx_corpus::EstepWork& es = c->es;
+    const uint64_t S = c->n_samples, N = c->n_bytes, K = es.soffs.size() - 1;
+    m->last_estep_pieces = 0;
+    m->last_estep_redo = 0;
+    if (K == 0) {
+        if (logz_sum) *logz_sum = 0.0;
+        m->last_alg_bytes = N + 8 * (S + 1) + 8ull * m->vocab_size;
+        return TGX_OK;
+    }
+    // A piece is a chain of trips (~7 us per trip of ~60 bytes): long snippets are cut where no match crosses (cuts.hip)
+    // so that the rows finish together — whenever the longest snippet's chain is a sizeable part of the pass
+    EstepPieces pc;
+    bool pieces = false;
+    {
+        uint32_t window = 2048;
+        if (const char* e = knob("TGX_ESTEP_WINDOW")) window = (uint32_t)std::min(1 << 20, std::max(256, atoi(e)));
+        const double longest0 = (double)(es.soffs[es.order[0] + 1] - es.soffs[es.order[0]]);
+        pieces = longest0 > 4.0 * window && longest0 * 0.12e-6 > 0.1 * ((double)N / 50e9);
+        if (const char* e = knob("TGX_ESTEP_PIECES")) pieces = atoi(e) != 0 && longest0 > (double)window;
+        if (pieces) {
+            tgx_status pst = ensure_estep_windows(m, c, window);
+            if (pst != TGX_OK) return pst;
+            pst = estep_pieces_build(m, c, m->d_trie, dropout, seed, &pc);
+            if (pst != TGX_OK) return pst;
+            m->last_estep_pieces = pc.n;
+        }
+    }
+    const uint64_t units = pieces ? pc.n : K;
+    const bool wide = m->n_tok7 > 65535u;
+    // (1 GiB, 32 000 entries: 12 waves x 4 positions per lane 32.5 ms, 10 waves 36.2, 8 waves 41.7; three positions per lane
+    // 34.2 / 38.5 / 44.3 and forty times the stretches without a cut in a trip — profiles/r04)
+    int ppl = wide ? 2 : 4, waves = 12;
+    if (const char* e = knob("TGX_EPPL")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4) ppl = v;
+    }
+    if (const char* e = knob("TGX_E7_WAVES")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 12) waves = v;
+    }
+    {   // fewer waves when the pass has fewer units than the chip has rows, so that they spread over the CUs
+        const uint64_t rows_wanted = (units + (uint64_t)m->num_cus - 1) / (uint64_t)m->num_cus;
+        waves = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)waves, (rows_wanted + 3) / 4));
+    }
+    uint32_t n_hot = std::min(m->n_tok7, tgx::estep7_max_hot(wide, waves, ppl, 160u * 1024u));
+    if (const char* e = knob("TGX_E7_HOT")) {
+        const int v = atoi(e);
+        if (v >= 0) n_hot = std::min(n_hot, (uint32_t)v);
+    }
+    const size_t ebytes = ((size_t)m->n_tok7 + 1) * 8 + 256, zbytes = (size_t)K * 8 + 256;
+    // (the redo list: a piece can leave several stretches, each longer than a trip's reach)
+    const uint64_t redo_cap = units + N / 32 + 16;
+    const size_t r8 = (size_t)redo_cap * 2 * 8 + 256, r4 = (size_t)redo_cap * 2 * 4 + 256;
+    double *d_exp = nullptr, *d_z = nullptr, *d_zsnip = nullptr;
+    void* d_work = nullptr;  // Estep7Work in device memory (kernels.h)
+    uint64_t *d_roffs = nullptr, *d_rbase = nullptr;
+    uint32_t *d_rsample = nullptr, *d_rsnip = nullptr;
+    auto cleanup = [&](tgx_status s2) {
+        if (s2 != TGX_OK) (void)hipStreamSynchronize(m->stream);
+        estep_pieces_free(m, pc);
+        pool_free(m->device, d_exp, ebytes);
+        pool_free(m->device, d_z, 256);
+        pool_free(m->device, d_work, 512);
+        pool_free(m->device, d_zsnip, zbytes);
+        pool_free(m->device, d_roffs, r8);
+        pool_free(m->device, d_rbase, r8);
+        pool_free(m->device, d_rsample, r4);
+        pool_free(m->device, d_rsnip, r4);
+        return s2;
+    };
+    static_assert(sizeof(tgx::Estep7Work) <= 512, "Estep7Work scratch");
+    if (pool_alloc(m->device, ebytes, (void**)&d_exp) != hipSuccess || pool_alloc(m->device, 256, (void**)&d_z) != hipSuccess ||
+        pool_alloc(m->device, 512, &d_work) != hipSuccess || pool_alloc(m->device, zbytes, (void**)&d_zsnip) != hipSuccess || pool_alloc(m->device, r8, (void**)&d_roffs) != hipSuccess ||
+        pool_alloc(m->device, r8, (void**)&d_rbase) != hipSuccess || pool_alloc(m->device, r4, (void**)&d_rsample) != hipSuccess ||
+        pool_alloc(m->device, r4, (void**)&d_rsnip) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (E-step scratch)"));
+    if (hipMemsetAsync(d_exp, 0, ebytes, m->stream) != hipSuccess || hipMemsetAsync(d_z, 0, 256, m->stream) != hipSuccess ||
+        hipMemsetAsync(d_zsnip, 0, zbytes, m->stream) != hipSuccess || hipMemsetAsync(m->d_ctrl + 3, 0x00, 24, m->stream) != hipSuccess ||
+        hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "E-step setup failed"));
+    tgx::Estep7Params p{};
+    tgx::Estep7Work& wk = p.host_work;
+    p.text = c->d_text;
+    p.work = reinterpret_cast<const tgx::Estep7Work*>(d_work);
+    wk.soffs = pieces ? pc.d_offs : es.d_soffs;
+    wk.order = pieces ? pc.d_order : es.d_order;
+    wk.n_snips = units;
+    wk.snip_sample = pieces ? pc.d_sample : es.d_ssample;
+    wk.snip_base = pieces ? pc.d_base : es.d_sbase;
+    wk.snip_of = pieces ? pc.d_snip : nullptr;
+    p.trie8t = m->d_trie8t;
+    p.n_slots = (uint32_t)m->flat.table.size();
+    p.root_base = m->root_base7;
+    p.wtab = m->d_wtab;
+    p.n_tok = m->n_tok7;
+    p.n_hot = n_hot;
+    p.expected = d_exp;
+    wk.zsnip = d_zsnip;
+    wk.logz_sum = d_z;
+    wk.queue = m->d_ctrl + 3;
+    wk.redo_count = m->d_ctrl + 4;
+    wk.range_flag = m->d_ctrl + 5;
+    wk.redo_offs = d_roffs;
+    wk.redo_sample = d_rsample;
+    wk.redo_base = d_rbase;
+    wk.redo_snip = d_rsnip;
+    wk.redo_cap = redo_cap;
+    p.dropout = dropout;
+    p.seed = seed;
+    {
+        const uint64_t avg = units ? N / units : 0;
+        p.claim_chunk = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, 4096 / std::max<uint64_t>(1, avg)));
+    }
+    const uint64_t rows_per_block = 4ull * (uint64_t)waves;
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((units + rows_per_block - 1) / rows_per_block, (uint64_t)m->num_cus));
+    unsigned long long* d_stamps = nullptr;
+    const size_t n_stamp_waves = (size_t)blocks * (size_t)waves;
+    if (const char* e = debug_on() ? getenv("TGX_STAMPS") : nullptr) {
+        if (*e == '7' && pool_alloc(m->device, n_stamp_waves * 64, (void**)&d_stamps) == hipSuccess) {
+            (void)hipMemsetAsync(d_stamps, 0, n_stamp_waves * 64, m->stream);
+            p.stamps = d_stamps;
+        }
+    }
+    {
+        const char* f = debug_on() ? getenv("TGX_FLAGS") : nullptr;
+        p.flags = f ? (uint32_t)atoi(f) : 0u;
+    }
+    time_begin(m, "estep7_kernel");
+    if (tgx::launch_estep7(p, wide, ppl, waves, blocks, m->stream) != hipSuccess) {
+        pool_free(m->device, d_stamps, n_stamp_waves * 64);
+        return cleanup(fail(TGX_ERR_DEVICE, "estep7 launch failed"));
+    }
+    time_end(m);
+    if (d_stamps) {  // diagnostic: mean ticks per trip and phase over all waves
+        std::vector<unsigned long long> hs(n_stamp_waves * 8);
+        const bool ok = hipStreamSynchronize(m->stream) == hipSuccess && hipMemcpy(hs.data(), d_stamps, n_stamp_waves * 64, hipMemcpyDeviceToHost) == hipSuccess;
+        pool_free(m->device, d_stamps, n_stamp_waves * 64);
+        if (ok) {
+            double sum[6] = {0, 0, 0, 0, 0, 0}, trips = 0;
+            for (size_t w = 0; w < n_stamp_waves; w++) {
+                for (int i = 0; i < 6; i++) sum[i] += (double)hs[w * 8 + i];
+                trips += (double)hs[w * 8 + 6];
+            }
+            fprintf(stderr, "[tgx] estep7 stamps (s_memtime ticks per wave-trip, %zu waves x ppl %d, %.0f trips): claim %.0f  walk %.0f  cut %.0f  forward %.0f  z %.0f  backward %.0f\n",
+                    n_stamp_waves, ppl, trips, sum[0] / trips, sum[1] / trips, sum[2] / trips, sum[3] / trips, sum[4] / trips, sum[5] / trips);
+        }
+    }
+    unsigned long long flag = 0, n_redo = 0;
+    if (hipMemcpyAsync(&flag, m->d_ctrl + 5, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(&n_redo, m->d_ctrl + 4, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "E-step pass failed: %s", hipGetErrorString(hipGetLastError())));
+    m->last_estep_redo = n_redo;
+    if (flag != 0) {  // a position nothing reaches, a value out of range: the pass belongs to the log-domain kernels
+        *fallback = true;
+        return cleanup(TGX_OK);
+    }
+    if (n_redo != 0) {
+        // the stretches the kernel could not close within a trip: estep7_redo_kernel, trips spilled to scratch
+        if (n_redo > redo_cap) return cleanup(fail(TGX_ERR_DEVICE, "E-step redo list longer than its buffers"));
+        std::vector<uint64_t> ro(2 * n_redo), tbase(n_redo + 1, 0);
+        if (hipMemcpy(ro.data(), d_roffs, 2 * n_redo * 8, hipMemcpyDeviceToHost) != hipSuccess) return cleanup(fail(TGX_ERR_DEVICE, "redo list read-back failed"));
+        for (uint64_t i = 0; i < n_redo; i++) {
+            if (ro[2 * i + 1] < ro[2 * i] || ro[2 * i + 1] > N) return cleanup(fail(TGX_ERR_DEVICE, "corrupt E-step redo list"));
+            tbase[i + 1] = tbase[i] + (ro[2 * i + 1] - ro[2 * i]) / 16 + 1;
+        }
+        const uint64_t TT = tbase[n_redo];
+        const size_t rs = wide ? 1024 : 512;
+        const size_t ab = (size_t)TT * 16 * 8 + 256, xb = (size_t)TT * 4 + 256, mb = (size_t)TT * rs + 256, tbb = (size_t)(n_redo + 1) * 8 + 256;
+        double* d_alpha = nullptr;
+        int32_t* d_aexp = nullptr;
+        unsigned char* d_ms = nullptr;
+        uint64_t* d_tbase = nullptr;
+        auto cleanup2 = [&](tgx_status s2) {
+            (void)hipStreamSynchronize(m->stream);
+            pool_free(m->device, d_alpha, ab);
+            pool_free(m->device, d_aexp, xb);
+            pool_free(m->device, d_ms, mb);
+            pool_free(m->device, d_tbase, tbb);
+            return s2;
+        };
+        if (pool_alloc(m->device, ab, (void**)&d_alpha) != hipSuccess || pool_alloc(m->device, xb, (void**)&d_aexp) != hipSuccess ||
+            pool_alloc(m->device, mb, (void**)&d_ms) != hipSuccess || pool_alloc(m->device, tbb, (void**)&d_tbase) != hipSuccess)
+            return cleanup(cleanup2(fail(TGX_ERR_DEVICE, "out of device memory (E-step redo scratch)")));
+        if (hipMemcpyAsync(d_tbase, tbase.data(), (n_redo + 1) * 8, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+            hipMemsetAsync(m->d_ctrl + 3, 0x00, 8, m->stream) != hipSuccess)
+            return cleanup(cleanup2(fail(TGX_ERR_DEVICE, "E-step redo setup failed")));
+        tgx::Estep7RedoParams q{};
+        q.text = c->d_text;
+        q.redo_offs = d_roffs;
+        q.redo_sample = d_rsample;
+        q.redo_base = d_rbase;
+        q.redo_snip = d_rsnip;
+        q.n_redo = n_redo;
+        q.tbase = d_tbase;
+        q.trie8t = m->d_trie8t;
+        q.n_slots = p.n_slots;
+        q.root_base = p.root_base;
+        q.wtab = m->d_wtab;
+        q.n_tok = m->n_tok7;
+        q.n_hot = std::min(std::min(m->n_tok7, tgx::estep7_redo_max_hot(wide)), n_hot);
+        q.expected = d_exp;
+        q.zsnip = d_zsnip;
+        q.logz_sum = d_z;
+        q.range_flag = m->d_ctrl + 5;
+        q.queue = m->d_ctrl + 3;
+        q.alpha = d_alpha;
+        q.aexp = d_aexp;
+        q.mscratch = d_ms;
+        q.dropout = dropout;
+        q.seed = seed;
+        time_begin(m, "estep7_redo_kernel");
+        const hipError_t le = tgx::launch_estep7_redo(q, wide, (uint32_t)m->num_cus, m->stream);
+        time_end(m);
+        if (le != hipSuccess) return cleanup(cleanup2(fail(TGX_ERR_DEVICE, "estep7 redo launch failed: %s", hipGetErrorString(le))));
+        if (hipMemcpyAsync(&flag, m->d_ctrl + 5, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess)
+            return cleanup(cleanup2(fail(TGX_ERR_DEVICE, "E-step redo pass failed")));
+        const tgx_status rst = cleanup2(TGX_OK);  // (synchronises the stream)
+        if (rst != TGX_OK) return cleanup(rst);
+        if (hipGetLastError() != hipSuccess) return cleanup(fail(TGX_ERR_DEVICE, "E-step redo pass failed"));
+        if (flag != 0) {
+            *fallback = true;
+            return cleanup(TGX_OK);
+        }
+    }
+    if (tgx::launch_snip_z_check(d_zsnip, K, m->d_ctrl + 1, m->stream) != hipSuccess) return cleanup(fail(TGX_ERR_DEVICE, "z check launch failed"));
+    std::vector<double> h((size_t)m->n_tok7 + 1);
+    double hz = 0.0;
+    if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(h.data(), d_exp, h.size() * 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipMemcpyAsync(&hz, d_z, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess)
+        return cleanup(fail(TGX_ERR_DEVICE, "E-step pass failed: %s", hipGetErrorString(hipGetLastError())));
+    m->last_alg_bytes = N + 8 * (S + 1) + 8ull * m->vocab_size;
+    const unsigned long long bad = m->h_ctrl[0];
+    if (bad != ~0ULL) {  // nothing of a failed pass reaches the caller's `expected`
+        const uint64_t smp = es.ssample[bad];
+        g_err_sample = smp;
+        g_err_pos = g_err_len = c->h_offs[smp + 1] - c->h_offs[smp];
+        return cleanup(fail(TGX_ERR_Z_NOT_NORMAL, "normalization constant is not a normal number (sample %llu, len=%llu)",
+                            (unsigned long long)smp, (unsigned long long)g_err_len));  // src/prune.rs:90-96
+    }
+    for (uint32_t r = 1; r <= m->n_tok7; r++) expected[m->id_of_rank[r]] += h[r];
+    if (logz_sum) *logz_sum = hz;
+    m->estep_calls++;
+    return cleanup(TGX_OK);
+}
+
+// E-step on the four-snippets-per-wave kernels (estep4.hip).  Caller holds m->mu and has
+// built the reversed trie.
+// `fallback` (vocabularies with tokens of 17..32 bytes only): set when the linear-domain kernels cannot do the
+// pass (a position without an incoming token, the f64 range left, an overflow list full) — there are no log-domain
+// rows4 kernels for such vocabularies, the caller goes on to the generic kernel; `expected` is untouched then.
+static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout,
+                              uint64_t seed, double* expected, double* logz_sum, bool* fallback) {
+    const bool long_tokens = m->lm > 16;
+    if (fallback) *fallback = false;
+    const uint64_t S = c->n_samples, N = c->n_bytes;
+    {
+        const tgx_status wst = ensure_estep_work(m, c, snippet_len);
+        if (wst != TGX_OK) return wst;
+    }
+    tgx_corpus::EstepWork& es = c->es;
     const std::vector<uint64_t>& soffs = es.soffs;
     const std::vector<uint32_t>& ssample = es.ssample;
     const std::vector<uint32_t>& order = es.order;
@@ -2248,31 +2684,8 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     // crosses — the lattice factorises there — and runs the linear-domain kernels on pieces of about `window` bytes.
     // Estimates as below (1 position per lane: forward 52 GB/s and 14.5 ms per 64 KiB of chain, backward 21 GB/s and
     // 29 ms); TGX_ESTEP_PIECES=0 / 1 forces, TGX_ESTEP_WINDOW sets the window.
-    struct Pieces {
-        uint64_t n = 0, longest = 0, cap = 0;
-        uint64_t *d_bound = nullptr, *d_pos = nullptr, *d_offs = nullptr, *d_base = nullptr;
-        uint32_t *d_flag = nullptr, *d_sample = nullptr, *d_snip = nullptr, *d_len = nullptr, *d_idx = nullptr, *d_len2 = nullptr, *d_order = nullptr;
-        void *d_scan = nullptr, *d_sort = nullptr;
-        double* d_zsnip = nullptr;
-        size_t scan_bytes = 0, sort_bytes = 0, zsnip_bytes = 0;
-    } pc;
-    auto free_pieces = [&]() {
-        pool_free(m->device, pc.d_bound, pc.cap * 8 + 256);
-        pool_free(m->device, pc.d_pos, (pc.cap + 1) * 8 + 256);
-        pool_free(m->device, pc.d_offs, (pc.cap + 1) * 8 + 256);
-        pool_free(m->device, pc.d_base, pc.cap * 8 + 256);
-        pool_free(m->device, pc.d_flag, (pc.cap + 1) * 4 + 256);
-        pool_free(m->device, pc.d_sample, pc.cap * 4 + 256);
-        pool_free(m->device, pc.d_snip, pc.cap * 4 + 256);
-        pool_free(m->device, pc.d_len, pc.cap * 4 + 256);
-        pool_free(m->device, pc.d_idx, pc.cap * 4 + 256);
-        pool_free(m->device, pc.d_len2, pc.cap * 4 + 256);
-        pool_free(m->device, pc.d_order, pc.cap * 4 + 256);
-        pool_free(m->device, pc.d_scan, pc.scan_bytes);
-        pool_free(m->device, pc.d_sort, pc.sort_bytes);
-        pool_free(m->device, pc.d_zsnip, pc.zsnip_bytes);
-        pc = Pieces{};
-    };
+    EstepPieces pc;
+    auto free_pieces = [&]() { estep_pieces_free(m, pc); };
     bool pieces = false;
     if (linear && K && m->lm <= 32) {
         uint32_t window = 2048;
@@ -2284,95 +2697,14 @@ static tgx_status estep_rows4(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         // 1 GiB 57.1 -> 57.2: the longest chains delay a pass well before they bound it — profiles/r03)
         pieces = longest0 > 4.0 * window && t_chain > 0.5 * t_thru;
         if (const char* e = knob("TGX_ESTEP_PIECES")) pieces = atoi(e) != 0 && longest0 > (double)window;
-        if (pieces && (es.window != window || !es.d_win_snip)) {
-            pool_free(c->device, es.d_win_snip, es.winbytes);
-            pool_free(c->device, es.d_win_k, es.winbytes);
-            es.d_win_snip = es.d_win_k = nullptr;
-            es.window = 0;
-            std::vector<uint32_t> ws, wk;
-            ws.reserve(K + N / window + 2);
-            wk.reserve(K + N / window + 2);
-            for (uint64_t k = 0; k < K; k++) {
-                const uint64_t len = soffs[k + 1] - soffs[k];
-                for (uint64_t j = 0; j * window < len; j++) {
-                    ws.push_back((uint32_t)k);
-                    wk.push_back((uint32_t)j);
-                }
-            }
-            es.n_windows = ws.size();
-            es.winbytes = es.n_windows * 4 + 256;
-            if (pool_alloc(c->device, es.winbytes, (void**)&es.d_win_snip) != hipSuccess ||
-                pool_alloc(c->device, es.winbytes, (void**)&es.d_win_k) != hipSuccess)
-                return fail(TGX_ERR_DEVICE, "out of device memory (E-step windows)");
-            if (hipMemcpyAsync(es.d_win_snip, ws.data(), es.n_windows * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
-                hipMemcpyAsync(es.d_win_k, wk.data(), es.n_windows * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
-                hipStreamSynchronize(m->stream) != hipSuccess)
-                return fail(TGX_ERR_DEVICE, "E-step window list upload failed");
-            es.window = window;
+        if (pieces) {
+            const tgx_status wst = ensure_estep_windows(m, c, window);
+            if (wst != TGX_OK) return wst;
         }
     }
     if (pieces) {
-        const uint64_t W = es.n_windows;
-        pc.cap = W;
-        pc.zsnip_bytes = (size_t)K * 8 + 256;
-        auto bad = [&](const char* what) {
-            (void)hipStreamSynchronize(m->stream);
-            free_pieces();
-            return fail(TGX_ERR_DEVICE, "E-step pieces: %s", what);
-        };
-        if (tgx::scan_temp_bytes(W, &pc.scan_bytes) != hipSuccess || tgx::piece_sort_temp_bytes(W, &pc.sort_bytes) != hipSuccess)
-            return bad("scratch sizes");
-        if (pool_alloc(m->device, W * 8 + 256, (void**)&pc.d_bound) != hipSuccess ||
-            pool_alloc(m->device, (W + 1) * 8 + 256, (void**)&pc.d_pos) != hipSuccess ||
-            pool_alloc(m->device, (W + 1) * 8 + 256, (void**)&pc.d_offs) != hipSuccess ||
-            pool_alloc(m->device, W * 8 + 256, (void**)&pc.d_base) != hipSuccess ||
-            pool_alloc(m->device, (W + 1) * 4 + 256, (void**)&pc.d_flag) != hipSuccess ||
-            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_sample) != hipSuccess ||
-            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_snip) != hipSuccess ||
-            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_len) != hipSuccess ||
-            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_idx) != hipSuccess ||
-            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_len2) != hipSuccess ||
-            pool_alloc(m->device, W * 4 + 256, (void**)&pc.d_order) != hipSuccess ||
-            (pc.scan_bytes && pool_alloc(m->device, pc.scan_bytes, &pc.d_scan) != hipSuccess) ||
-            (pc.sort_bytes && pool_alloc(m->device, pc.sort_bytes, &pc.d_sort) != hipSuccess) ||
-            pool_alloc(m->device, pc.zsnip_bytes, (void**)&pc.d_zsnip) != hipSuccess)
-            return bad("out of device memory");
-        tgx::CutParams q{};
-        q.text = c->d_text;
-        q.soffs = d_soffs;
-        q.snip_sample = d_ssample;
-        q.snip_base = d_sbase;
-        q.win_snip = es.d_win_snip;
-        q.win_k = es.d_win_k;
-        q.n_windows = W;
-        q.window = es.window;
-        q.trie = m->d_trie_w;
-        q.root = m->flat.table[0].base & ~tgx::kTerminalBit;
-        q.lmx = m->lm > 16 ? 32u : 16u;
-        q.dropout = dropout;
-        q.seed = seed;
-        q.bound = pc.d_bound;
-        q.flag = pc.d_flag;
-        unsigned long long* const d_longest = m->d_ctrl + 6;
-        time_begin(m, "cut_windows_kernel");
-        if (tgx::launch_cut_windows(q, m->stream) != hipSuccess) return bad("cut kernel launch failed");
-        time_end(m);
-        time_begin(m, "piece_list");
-        if (hipMemsetAsync(d_longest, 0, 8, m->stream) != hipSuccess || hipMemsetAsync(pc.d_zsnip, 0, pc.zsnip_bytes, m->stream) != hipSuccess ||
-            tgx::launch_scan(pc.d_flag, pc.d_pos, W, pc.d_scan, pc.scan_bytes, m->stream) != hipSuccess ||
-            tgx::launch_cut_scatter(q, pc.d_pos, N, pc.d_offs, pc.d_sample, pc.d_base, pc.d_snip, m->stream) != hipSuccess ||
-            tgx::launch_piece_len(pc.d_offs, pc.d_pos + W, pc.d_len, pc.d_idx, d_longest, W, m->stream) != hipSuccess ||
-            tgx::piece_sort(pc.d_sort, pc.sort_bytes, pc.d_len, pc.d_len2, pc.d_idx, pc.d_order, W, m->stream) != hipSuccess)
-            return bad("piece list kernels failed");
-        time_end(m);
-        unsigned long long h_n = 0, h_longest = 0;
-        if (hipMemcpyAsync(&h_n, pc.d_pos + W, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
-            hipMemcpyAsync(&h_longest, d_longest, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
-            hipStreamSynchronize(m->stream) != hipSuccess)
-            return bad("piece list read-back failed");
-        if (h_n < K || h_n > W) return bad("inconsistent piece count");
-        pc.n = h_n;
-        pc.longest = h_longest;
+        const tgx_status pst = estep_pieces_build(m, c, m->d_trie_w, dropout, seed, &pc);
+        if (pst != TGX_OK) return pst;
         m->last_estep_pieces = pc.n;
     } else {
         m->last_estep_pieces = 0;
@@ -2635,9 +2967,20 @@ tgx_status tgx_estep(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double d
     std::lock_guard<std::mutex> lk(m->mu);
     std::lock_guard<std::mutex> lkc(c->mu);
     HIP_TRY(hipSetDevice(m->device));
-    tgx_status st = ensure_reverse_trie(m);
-    if (st != TGX_OK) return st;
     m->n_timed = 0;
+    tgx_status st = TGX_OK;
+    {   // round 4: one walk per position (estep7.hip); TGX_ESTEP=chain / log and TGX_PATH=rows4 / fused keep the older kernels
+        const char* force = knob("TGX_PATH");
+        const char* fe = knob("TGX_ESTEP");
+        if (m->scores_finite && m->lm <= 16 && m->vocab_size && !force && !fe) {
+            bool fallback = false;
+            st = estep_fused(m, c, snippet_len, dropout, seed, expected, logz_sum, &fallback);
+            if (st != TGX_OK || !fallback) return st;
+            m->n_timed = 0;
+        }
+    }
+    st = ensure_reverse_trie(m);
+    if (st != TGX_OK) return st;
     const uint64_t S = c->n_samples, N = c->n_bytes;
     {
         const char* force = knob("TGX_PATH");
@@ -2747,6 +3090,7 @@ uint64_t tgx_last_algorithmic_bytes(const tgx_model* m) { return m ? m->last_alg
 uint64_t tgx_last_encode_redo_samples(const tgx_model* m) { return m ? m->last_redo_samples : 0; }
 uint64_t tgx_last_encode_long_samples(const tgx_model* m) { return m ? m->last_long_samples : 0; }
 uint64_t tgx_last_estep_pieces(const tgx_model* m) { return m ? m->last_estep_pieces : 0; }
+uint64_t tgx_last_estep_redo(const tgx_model* m) { return m ? m->last_estep_redo : 0; }
 uint32_t tgx_last_encode_corun_cus(const tgx_model* m) { return m ? m->last_corun_cus : 0; }
 uint32_t tgx_model_score_values(const tgx_model* m) { return m && m->have_trie8 ? m->n_values : 0u; }
 uint32_t tgx_last_encode_hot_values(const tgx_model* m) { return m ? m->last_n_hot : 0u; }

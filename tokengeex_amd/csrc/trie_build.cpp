@@ -358,6 +358,86 @@ uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const u
     return found;
 }
 
+// ---- token-ranked 8-byte records (estep7_kernel) -----------------------------------------------------------------
+void build_trie8t(const FlatTrie& ft, const uint64_t* offs, const double* scores, Trie8T* out) {
+    const uint32_t n_slots = (uint32_t)ft.table.size();
+    out->ok = false;
+    out->rec.clear();
+    out->w.clear();
+    out->id_of_rank.clear();
+    out->n_tok = 0;
+    if (n_slots > kTrie8TMaxSlots) return;
+    // the tokens that can match (those that own a terminal slot), by descending exp(score) / length; ties by id
+    struct Key {
+        double weight;
+        uint32_t id;
+    };
+    std::vector<Key> keys;
+    keys.reserve(n_slots / 2);
+    for (uint32_t t = 0; t < n_slots; t++) {
+        const uint32_t id = ft.tokid[t];
+        if (id == kNoToken) continue;
+        const double len = (double)std::max<uint64_t>(1, offs[id + 1] - offs[id]);
+        double w = std::exp(scores[id]) / len;
+        if (!(w == w)) w = 0.0;
+        keys.push_back(Key{w, id});
+    }
+    const auto hotter = [](const Key& a, const Key& b) { return a.weight != b.weight ? a.weight > b.weight : a.id < b.id; };
+    const size_t head = std::min<size_t>(keys.size(), kTrie8TSortedRanks);
+    if (head < keys.size()) {
+        std::nth_element(keys.begin(), keys.begin() + (long)head, keys.end(), hotter);
+        std::sort(keys.begin() + (long)head, keys.end(), [](const Key& a, const Key& b) { return a.id < b.id; });
+    }
+    std::sort(keys.begin(), keys.begin() + (long)head, hotter);
+    const uint32_t n_tok = (uint32_t)keys.size();
+    out->n_tok = n_tok;
+    out->w.assign((size_t)n_tok + 1, 0.0);
+    out->id_of_rank.assign((size_t)n_tok + 1, kNoToken);
+    uint32_t max_id = 0;
+    for (const Key& k : keys) max_id = std::max(max_id, k.id);
+    std::vector<uint32_t> rank_of((size_t)max_id + 1, 0u);
+    for (uint32_t r = 0; r < n_tok; r++) {
+        rank_of[keys[r].id] = r + 1u;
+        out->id_of_rank[r + 1u] = keys[r].id;
+        out->w[r + 1u] = std::exp(scores[keys[r].id]);  // the same function of the same double as the 16-byte tables' weights
+    }
+    out->rec.assign(n_slots, Trie8TRec{0, 0});
+    for (uint32_t t = 0; t < n_slots; t++) {
+        Trie8TRec& q = out->rec[t];
+        const bool used = t != 0 && ft.table[t].check != kNoParent;
+        if (used) {
+            const uint32_t base = ft.inner[t] ? (ft.table[t].base & ~kTerminalBit) : kTrie8LeafBase;
+            q.rec = base | ((uint32_t)ft.label[t] << 24);
+            q.tok = ft.tokid[t] != kNoToken ? rank_of[ft.tokid[t]] : 0u;
+        } else {  // unused slots (and the root's own) can never pass the label check: see BlockAlloc::add_block
+            q.rec = kTrie8LeafBase | (((t ^ 0xFFu) & 0xFFu) << 24);
+            q.tok = 0;
+        }
+    }
+    out->root_base = ft.inner[0] ? (ft.table[0].base & ~kTerminalBit) : kTrie8LeafBase;
+    out->ok = true;
+}
+
+// host twin of estep7_kernel's walk: ids of the tokens that are prefixes of s
+uint64_t trie8t_common_prefix_search(const Trie8T& t8, const uint8_t* s, uint64_t n, uint32_t* ids, uint32_t* lens, uint64_t cap) {
+    uint32_t t = n ? (t8.root_base ^ s[0]) : 0u;
+    uint64_t found = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (t >= t8.rec.size()) break;
+        const uint32_t r = t8.rec[t].rec;
+        if ((r >> 24) != s[i]) break;
+        if (t8.rec[t].tok) {
+            if (found < cap) {
+                ids[found] = t8.id_of_rank[t8.rec[t].tok];
+                lens[found] = (uint32_t)(i + 1);
+            }
+            found++;
+        }
+        if (i + 1 < n) t = (r ^ (uint32_t)s[i + 1]) & 0xFFFFFFu;
+    }
+    return found;
+}
+
 static bool fill_tok_hash(const uint8_t* bytes, const uint64_t* offs, uint32_t vocab_size, TokHashTable* out) {
     std::fill(out->slots.begin(), out->slots.end(), TokHashEntry{0, 0, 0});
     for (uint32_t id = 0; id < vocab_size; id++) {

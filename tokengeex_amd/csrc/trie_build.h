@@ -82,6 +82,29 @@ void build_trie8(const FlatTrie& ft, const uint64_t* offs, const double* scores,
 uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const uint8_t* s, uint64_t n, uint32_t* ids,
                                     uint32_t* lens, uint64_t cap);
 
+// Records of estep7_kernel (estep7.hip) over the SAME slot assignment: {base | label << 24, rank of the token that ends
+// here (0: none)}.  The child by byte c of a node is the record at byte offset 8 * ((rec ^ c) & 0xFFFFFF), valid iff its
+// label is c (exact for the reasons given above; 2^24 slots).  Tokens are ranked by exp(score) / length — how often they
+// are expected to match — because the first ranks' weights and expected-count sums live in the blocks' LDS; only the
+// first `sorted_ranks` ranks are in that order (the kernels never keep more in LDS), the others follow in id order.
+// w[r] = exp(score of the token of rank r) (w[0] = 0: "no token"), id_of_rank[r] its vocabulary id.
+struct Trie8TRec {
+    uint32_t rec;  // base | label << 24
+    uint32_t tok;  // rank of the token, 0: no token ends here
+};
+constexpr uint32_t kTrie8TMaxSlots = 1u << 24;
+constexpr uint32_t kTrie8TSortedRanks = 16384u;
+struct Trie8T {
+    std::vector<Trie8TRec> rec;        // n_slots
+    std::vector<double> w;             // n_tok + 1
+    std::vector<uint32_t> id_of_rank;  // n_tok + 1 ([0] unused)
+    uint32_t root_base = 0;
+    uint32_t n_tok = 0;                // tokens that own a slot (duplicates and empty tokens do not)
+    bool ok = false;
+};
+void build_trie8t(const FlatTrie& ft, const uint64_t* offs, const double* scores, Trie8T* out);
+uint64_t trie8t_common_prefix_search(const Trie8T& t8, const uint8_t* s, uint64_t n, uint32_t* ids, uint32_t* lens, uint64_t cap);
+
 // Token-bytes -> id hash table (tokens of 1..32 bytes): lets the trace kernel turn a
 // (start, length) pair straight into a token id with one probe instead of carrying a trie
 // handle through the DP.  Open addressing, linear probing, capacity a power of two >= 2V;
