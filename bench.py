@@ -45,7 +45,14 @@ def main() -> None:
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive tgx_encode_batch measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU baseline leg")
     ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal on a one-GPU box: every rank uses cuda:0 and the ranks meet over gloo")
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0")
+    ap.add_argument("--collective", default="gloo", choices=["gloo", "nccl"],
+                    help="backend of the barrier and of the three timing scalars at N > 1: gloo on CPU tensors (the default — the "
+                         "path shards with no data-path collective, north_star: no RCCL needed, and it is what the tests run) "
+                         "or nccl (RCCL over xGMI)")
+    ap.add_argument("--no-estep", action="store_true", help="skip the E-step sub-record (prune's pass over the same corpus)")
+    ap.add_argument("--estep-steps", type=int, default=3)
+    ap.add_argument("--no-distinct", action="store_true", help="skip the encode passes with every token its own score")
     ap.add_argument("--master-port", type=int, default=29533)
     args = ap.parse_args()
 
@@ -76,7 +83,7 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29533")
         import torch.distributed as dist_mod
         dist = dist_mod
-        if args.single_device:
+        if args.collective == "gloo" or args.single_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
@@ -88,7 +95,7 @@ def main() -> None:
     from tokengeex_amd import synth
 
     dev = 0 if args.single_device else local_rank
-    coll_dev = "cpu" if args.single_device else f"cuda:{dev}"  # where the timing collectives' tensors live
+    coll_dev = "cpu" if (args.collective == "gloo" or args.single_device) else f"cuda:{dev}"  # where the timing collectives' tensors live
     if tgx.device_count() <= dev:
         raise SystemExit("bench.py needs a GPU (no usable HIP device); there is no CPU fallback")
 
@@ -149,6 +156,60 @@ def main() -> None:
 
     from tokengeex_amd import dist as tdist
     max_elapsed, tot_bytes, tot_tokens = tdist.aggregate_timing(elapsed, n_bytes, n_tokens, dist, coll_dev)
+
+    # ---- the same encode with every token its own score (what an M-step or merge leaves: any trained vocabulary);
+    # reported as `distinct_scores_mb_s`, never as `value`
+    distinct = None
+    if not args.no_distinct and not args.distinct_scores:
+        sc2 = scores + np.random.default_rng(5).uniform(-0.4, 0.4, len(toks))
+        m2 = tgx.NativeModel(toks, sc2, device=dev)
+        for _ in range(max(1, args.warmup)):
+            m2.encode_corpus(corpus).free()
+        sync_all()
+        t2 = time.perf_counter()
+        k2: dict[str, float] = {}
+        for _ in range(args.steps):
+            m2.encode_corpus(corpus).free()
+            for k, v in m2.last_kernel_times().items():
+                k2[k] = k2.get(k, 0.0) + v
+        sync_all()
+        e2 = time.perf_counter() - t2
+        mx2, tb2, _ = tdist.aggregate_timing(e2, n_bytes, 0, dist, coll_dev)
+        distinct = {"distinct_scores_mb_s": round(tb2 * max(1, args.steps) / mx2 / 1e6, 2),
+                    "distinct_scores_kernel_ms_per_step": {k: round(v / max(1, args.steps), 3) for k, v in k2.items()},
+                    "distinct_scores_lds_values": m2.last_encode_hot_values()}
+        m2.free()
+
+    # ---- E-step sub-record (src/prune.rs:64-120 over the same resident corpus: BASELINE.json configs[3]'s pass)
+    estep = None
+    if not args.no_estep and args.max_token_length <= 16:
+        me = tgx.NativeModel(toks, scores, device=dev, for_estep=True)
+        expected, logz = me.estep(corpus)  # warm-up (builds the E-step tables)
+        ek: dict[str, float] = {}
+        sync_all()
+        t3 = time.perf_counter()
+        for _ in range(args.estep_steps):
+            expected, logz = me.estep(corpus)
+            for k, v in me.last_kernel_times().items():
+                ek[k] = ek.get(k, 0.0) + v
+        sync_all()
+        e3 = time.perf_counter() - t3
+        mx3, tb3, _ = tdist.aggregate_timing(e3, n_bytes, 0, dist, coll_dev)
+        es = max(1, args.estep_steps)
+        e_alg = me.last_algorithmic_bytes()  # N + 8 (S + 1) + 8 V
+        eper = {k: v / es for k, v in ek.items()}
+        e_pass = sum(eper.values())
+        e_dom = max(eper, key=eper.get) if eper else "estep7_kernel"
+        e_ach = e_alg / (e_pass * 1e-3) / 1e9 if e_pass > 0 else 0.0
+        estep = {"value": round(tb3 * es / mx3 / 1e6, 2), "unit": "MB/s", "ms_per_step": round(mx3 / es * 1e3, 3), "steps": es,
+                 "kernel_ms_per_step": {k: round(v, 3) for k, v in eper.items()},
+                 "pieces": me.last_estep_pieces(), "redo_stretches": me.last_estep_redo(), "logz_sum": logz,
+                 "roofline": {"bound": "hbm", "kernel": e_dom, "kernel_ms": round(eper.get(e_dom, 0.0), 3), "pass_kernels_ms": round(e_pass, 3),
+                              "achieved": round(e_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(e_ach / HBM_PEAK_GBS, 5),
+                              "traffic": None, "algorithmic_bytes_per_launch": int(e_alg)}}
+        if rank == 0 and not args.no_cpu_baseline:
+            estep["cpu_baseline"] = cpu_baseline_estep(toks, scores, flat, offs, me, min(args.cpu_seconds, 10.0))
+        me.free()
 
     # ---- PCIe-inclusive rate of the host-buffer entry point (tgx_encode_batch + copies of ids and offsets
     # into caller memory), rank 0 only, after the timed region.  Reported as `e2e_mb_s`, never as `value`.
@@ -246,6 +307,10 @@ def main() -> None:
         }
         if e2e:
             out.update(e2e)
+        if distinct:
+            out.update(distinct)
+        if estep:
+            out["estep"] = estep
         if not args.no_cpu_baseline:  # rank 0 only; the other ranks have left the timed region
             out["cpu_baseline"] = cpu_baseline(toks, scores, flat, offs, model, args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -297,6 +362,42 @@ def cpu_baseline(toks, scores, flat, offs, model, target_seconds: float) -> dict
             "tokens_per_s": round(float(ids.size) / dt, 1),
             "value_1thread": round(float(offs[k1]) / dt1 / 1e6, 2),
             "sample_1thread": f"first {k1} samples ({int(offs[k1])} bytes), 1 thread, {dt1:.1f} s"}
+
+
+def cpu_baseline_estep(toks, scores, flat, offs, model, target_seconds: float) -> dict:
+    """The CPU oracle's E-step (the reference's f64 log-domain arithmetic, src/lattice.rs:245-333) on a bounded prefix of
+    the same corpus with all host cores, and the GPU's expected counts against it on that prefix."""
+    import numpy as np
+
+    import tokengeex_amd as tgx
+    from oracle import oracle as orc
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
+    ora = orc.OracleModel(toks, scores)
+    k = max(1, min(int(np.searchsorted(offs, 1 << 20)), offs.size - 1))
+    t = time.perf_counter()
+    ora.estep_flat(flat[: int(offs[k])], offs[: k + 1], threads=cores)
+    rate = float(offs[k]) / (time.perf_counter() - t)
+    k = max(1, min(int(np.searchsorted(offs, int(min(float(flat.size), rate * target_seconds)))), offs.size - 1))
+    sf, so = flat[: int(offs[k])], offs[: k + 1]
+    t = time.perf_counter()
+    st, want, wz, _ = ora.estep_flat(sf, so, threads=cores)
+    dt = time.perf_counter() - t
+    cs = tgx.NativeCorpus(sf, so, device=model.device)
+    got, gz = model.estep(cs)
+    cs.free()
+    longest = int(np.diff(so.astype(np.int64)).max())
+    rtol = 1.2e-8 * max(1.0, min(81920, longest) / 4096.0)  # the oracle's own rounding: tests/test_estep_pairs_gpu.py
+    ok = bool(st == orc.OK and np.allclose(got, want, rtol=rtol, atol=1e-12) and np.array_equal(got != 0, want != 0)
+              and abs(gz - wz) <= 1e-12 * abs(wz) + 1e-9)
+    if not ok:
+        raise SystemExit("PARITY FAILURE: GPU expected counts differ from the CPU oracle on the E-step baseline sample")
+    return {"value": round(float(sf.size) / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": "port",
+            "sample": f"first {k} samples ({sf.size} bytes) of the same corpus, {cores} threads, {dt:.1f} s; GPU expected counts on "
+                      f"this sample within rtol {rtol:.1e} / atol 1e-12 of the oracle's, same support, log Z to 1e-12: {ok}"}
 
 
 if __name__ == "__main__":

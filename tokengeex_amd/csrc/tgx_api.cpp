@@ -1056,8 +1056,13 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
     // TGX_MODEL_FOR_ESTEP: the double-array of the REVERSED tokens (backward sweep of the E-step) is built
     // on a second host thread while this one builds the forward table — `prune` makes a new model for every
     // EM sub-iteration (src/prune.rs:48), and at 500 K tokens each table takes ~0.4 s of host time
+    // (round 4: not for vocabularies estep7_kernel serves — tokens of at most 16 bytes, scores within +-300: its E-step
+    // walks the forward table only; the reversed table is then built if a pass ever falls back to the chained kernels)
+    bool fused_estep = vocab_size != 0;
+    for (uint32_t i = 0; i < vocab_size && fused_estep; i++)
+        fused_estep = offs[i + 1] - offs[i] <= 16 && scores[i] >= -300.0 && scores[i] <= 300.0;
     std::thread rev_builder;
-    if ((flags & TGX_MODEL_FOR_ESTEP) && vocab_size)
+    if ((flags & TGX_MODEL_FOR_ESTEP) && vocab_size && !fused_estep)
         rev_builder = std::thread([m, bytes, offs, scores, vocab_size]() {
             const uint64_t o0 = offs[0];
             std::vector<uint8_t> rev((size_t)(offs[vocab_size] - o0));
@@ -1227,6 +1232,8 @@ tgx_status tgx_model_create_derived(const tgx_model* parent, const uint32_t* kee
             }
         }
     };
+    // (the parent's reversed table is built, if ever, under its lock: ensure_reverse_trie)
+    std::unique_lock<std::mutex> parent_lock(const_cast<tgx_model*>(parent)->mu);
     std::thread rev_deriver;
     const bool want_rev = (flags & TGX_MODEL_FOR_ESTEP) && parent->rev_host_built && n_keep;
     if (want_rev) rev_deriver = std::thread([&]() { derive(parent->flat_rev, &m->flat_rev); });
@@ -1245,6 +1252,7 @@ tgx_status tgx_model_create_derived(const tgx_model* parent, const uint32_t* kee
         rev_deriver.join();
         m->rev_host_built = true;
     }
+    parent_lock.unlock();
     return finish_model_create(m, bytes.data(), offs.data(), scores, n_keep, parent->device, flags, out);
 }
 
@@ -2414,15 +2422,17 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         m->last_alg_bytes = N + 8 * (S + 1) + 8ull * m->vocab_size;
         return TGX_OK;
     }
-    // A piece is a chain of trips (~7 us per trip of ~60 bytes): long snippets are cut where no match crosses (cuts.hip)
-    // so that the rows finish together — whenever the longest snippet's chain is a sizeable part of the pass
+    // A piece is a chain of trips (~0.12 us per byte: a 64 KiB snippet takes ~8 ms) while a pass runs at ~33 GB/s: long
+    // snippets are cut where no match crosses (cuts.hip) when the longest chain is a sizeable part of the pass — 256 MiB:
+    // 21.2 -> 8.6 ms; 1 GiB: 33.6 ms uncut, 34.3 cut (the cut search and the piece list cost 0.5 - 0.8 ms).  Windows of
+    // 4 KiB: 8.64 ms at 256 MiB against 8.91 with 2 KiB and 9.23 with 1 KiB (profiles/r04)
     EstepPieces pc;
     bool pieces = false;
     {
-        uint32_t window = 2048;
+        uint32_t window = 4096;
         if (const char* e = knob("TGX_ESTEP_WINDOW")) window = (uint32_t)std::min(1 << 20, std::max(256, atoi(e)));
         const double longest0 = (double)(es.soffs[es.order[0] + 1] - es.soffs[es.order[0]]);
-        pieces = longest0 > 4.0 * window && longest0 * 0.12e-6 > 0.1 * ((double)N / 50e9);
+        pieces = longest0 > 4.0 * window && longest0 * 0.12e-6 > 0.4 * ((double)N / 33e9);
         if (const char* e = knob("TGX_ESTEP_PIECES")) pieces = atoi(e) != 0 && longest0 > (double)window;
         if (pieces) {
             tgx_status pst = ensure_estep_windows(m, c, window);
@@ -2449,6 +2459,8 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         const uint64_t rows_wanted = (units + (uint64_t)m->num_cus - 1) / (uint64_t)m->num_cus;
         waves = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)waves, (rows_wanted + 3) / 4));
     }
+    // (32-bit entries take twice the LDS: the geometry must leave room for a table worth having)
+    while (waves > 1 && tgx::estep7_max_hot(wide, waves, ppl, 160u * 1024u) < 1024u) waves--;
     uint32_t n_hot = std::min(m->n_tok7, tgx::estep7_max_hot(wide, waves, ppl, 160u * 1024u));
     if (const char* e = knob("TGX_E7_HOT")) {
         const int v = atoi(e);

@@ -71,7 +71,11 @@ class ModelVocabularyPruner:
         (tgx_model_create_derived: no double-array is rebuilt), from scratch otherwise (duplicate tokens)."""
         try:
             return parent.derive(idx, arrays[1], for_estep=for_estep)
-        except _lib.TokenGeeXError:
+        except _lib.TokenGeeXError as exc:
+            # only "the parent has duplicate tokens" (TGX_ERR_UNSUPPORTED) means "build it from scratch": a device failure or a
+            # bad index list must surface (and every rank of a multi-rank run takes the same path)
+            if exc.status != _lib.ERR_UNSUPPORTED:
+                raise
             return self._model(arrays, for_estep=for_estep)
 
     @staticmethod

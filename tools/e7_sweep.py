@@ -24,7 +24,10 @@ for mib in [int(a) for a in sys.argv[2:]] or [256, 1024]:
     c = tgx.NativeCorpus(flat, offs)
     print(f"== {which}: {mib} MiB, {offs.size - 1} samples", flush=True)
     cfgs = [dict(TGX_ESTEP="chain"), dict()]
-    for w, p in ((8, 4), (6, 4), (10, 4), (12, 4), (8, 3), (10, 3), (12, 3), (12, 2), (8, 2)):
+    geoms = ((8, 4), (6, 4), (10, 4), (12, 4), (8, 3), (10, 3), (12, 3), (12, 2), (8, 2))
+    if len(toks) > 65535:  # 32-bit entries: 4 KiB per wave and 16 positions per lane
+        geoms = ((5, 4), (6, 4), (7, 4), (8, 4), (6, 3), (7, 3), (8, 3), (9, 3), (10, 3), (12, 2))
+    for w, p in geoms:
         cfgs.append(dict(TGX_E7_WAVES=str(w), TGX_EPPL=str(p)))
     cfgs += [dict(TGX_ESTEP_PIECES="0"), dict(TGX_ESTEP_PIECES="1", TGX_ESTEP_WINDOW="1024"), dict(TGX_ESTEP_PIECES="1", TGX_ESTEP_WINDOW="4096"),
              dict(TGX_E7_HOT="2048"), dict(TGX_E7_HOT="4096")]
