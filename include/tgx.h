@@ -199,6 +199,16 @@ tgx_status tgx_encode_batch_host(tgx_model *m, const uint8_t *text, const uint64
                                  double dropout, uint64_t seed, uint32_t *ids_out, uint64_t ids_cap,
                                  uint64_t *offs_out, uint64_t *n_tokens);
 
+/* The same from ONE host process over SEVERAL devices: `models` holds one handle per GPU (tgx_model_create with
+ * device = 0 .. n - 1, the same vocabulary), the batch is cut at sample boundaries into byte-balanced shards, every shard
+ * runs tgx_encode_batch_host on a host thread of its own, and ids / offsets come back packed in sample order — what the
+ * reference's single-call batch (src/tokenizer.rs:102-111) becomes on a node with several GPUs.  No collective.
+ * ids_out must hold one id per input byte (ids_cap >= bytes).  With dropout > 0 the keep decisions hash a sample's index
+ * in its shard.  The lowest failing sample of the batch is reported. */
+tgx_status tgx_encode_batch_multi(tgx_model *const *models, uint32_t n_models, const uint8_t *text, const uint64_t *offs,
+                                  uint64_t n_samples, double dropout, uint64_t seed, uint32_t *ids_out, uint64_t ids_cap,
+                                  uint64_t *offs_out, uint64_t *n_tokens);
+
 uint64_t tgx_result_num_samples(const tgx_result *r);
 uint64_t tgx_result_num_tokens(const tgx_result *r);
 /* Host pointers (copied from the device on first use); valid until tgx_result_free. */

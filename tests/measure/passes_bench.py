@@ -13,9 +13,11 @@ if V == 500000:  # the committed vocabulary of BASELINE.json configs[3] (tests/g
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from util import load_vocab_500k
     toks, scores = load_vocab_500k()
+elif V in (32000, 65536):  # the committed 64 MiB-slice vocabularies (bench.py's)
+    toks, scores, _ = synth.load_spec_vocab(V)
 else:
-    vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
-    toks, scores = synth.build_vocab(vflat[: 2 << 20], V, 16)
+    vflat, _ = synth.make_corpus(8 << 20, "mixed", seed_offset=0)
+    toks, scores = synth.build_vocab(vflat, V, 16)
 if len(toks) != V:  # a slice too small for V tokens once produced a "500 K" record of 190 730 tokens
     raise SystemExit(f"vocabulary has {len(toks)} tokens, {V} were asked for")
 flat, offs = synth.make_corpus(size << 20, "mixed", seed_offset=1000)
@@ -37,6 +39,9 @@ out["count_tokens"] = {"wall_ms": dt * 1e3, "kernel_ms": m.last_kernel_times(), 
 # pair scan
 dt, (keys, counts) = timed(lambda: m.count_pairs(c))
 out["count_pairs"] = {"wall_ms": dt * 1e3, "kernel_ms": m.last_kernel_times(), "GB_per_s": flat.size / dt / 1e9, "distinct_pairs": int(keys.size)}
+# the pair scan as the merge driver asks for it: the 2^18 most frequent pairs only (tgx_count_pairs_top)
+dt, (tk, tc, total) = timed(lambda: m.count_pairs_top(c, 1 << 18))
+out["count_pairs_top"] = {"wall_ms": dt * 1e3, "kernel_ms": m.last_kernel_times(), "GB_per_s": flat.size / dt / 1e9, "pairs_returned": int(tk.size), "distinct_pairs": int(total)}
 # CPU oracle on a bounded prefix (all host cores) + parity
 k = int(np.searchsorted(offs, min(flat.size, cpu_mib << 20))); sf, so = flat[: int(offs[k])], offs[: k + 1]
 ora = orc.OracleModel(toks, scores)

@@ -28,8 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_config0_10mb_ascii_32k_vocab():
-    vflat, _ = synth.make_corpus(4 << 20, "ascii", seed_offset=0)
-    toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
+    toks, scores, _ = synth.load_spec_vocab(32000)   # the committed 64 MiB-slice vocabulary
     assert len(toks) == 32000
     flat, offs = synth.make_corpus(10_000_000, "ascii", seed_offset=1000)
     assert abs(int(flat.size) - 10_000_000) < 70_000 and int(flat.max()) < 128

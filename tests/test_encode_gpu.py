@@ -195,6 +195,31 @@ def test_large_vocabularies_64k_and_200k():
         np.testing.assert_array_equal(nat.count_tokens(corpus), ora.count_tokens_flat(sub_flat, sub_offs, threads=8))
 
 
+@pytest.mark.parametrize("size", [32000, 65536])
+def test_committed_spec_vocabularies_against_the_oracle(size):
+    """The vocabularies bench.py runs on (the generate stand-in over a 64 MiB slice, committed as
+    tests/golden/vocab_32000.npz / vocab_65536.npz; configs[1] and configs[2]): encode, frequency pass, pair scan and
+    E-step against the oracle on a few MiB."""
+    toks, scores, slice_mib = synth.load_spec_vocab(size)
+    assert len(toks) == size and slice_mib == 64
+    flat, offs = synth.make_corpus(6 << 20, "mixed", seed_offset=1000)
+    nat, ora = _pair(toks, scores)
+    assert_same_encoding(nat, ora, flat, offs)
+    assert "encode5_kernel" in nat.last_kernel_times() or "encode6_kernel" in nat.last_kernel_times()
+    corpus = tgx.NativeCorpus(flat, offs)
+    np.testing.assert_array_equal(nat.count_tokens(corpus), ora.count_tokens_flat(flat, offs, threads=8))
+    keys, counts = nat.count_pairs(corpus)
+    wk, wc = ora.count_pairs_flat(flat, offs, threads=8)
+    np.testing.assert_array_equal(keys, wk)
+    np.testing.assert_array_equal(counts, wc)
+    got, gz = nat.estep(corpus)
+    st, want, wz, _ = ora.estep_flat(flat, offs, threads=8)
+    assert st == orc.OK
+    longest = int(np.diff(offs.astype(np.int64)).max())
+    np.testing.assert_allclose(got, want, rtol=1.2e-8 * max(1.0, longest / 4096.0), atol=1e-12)
+    assert np.array_equal(got != 0, want != 0) and abs(gz - wz) <= 1e-12 * abs(wz) + 1e-9
+
+
 def test_both_kernel_paths_agree(monkeypatch):
     """The four-samples-per-wave path and the one-sample-per-wave path (TGX_PATH=fused)."""
     flat, offs, toks, scores = corpus_and_vocab(1 << 20, "mixed", 5000, 16, seed_offset=3)
@@ -401,8 +426,7 @@ def test_full_size_properties():
     oracle pass of that size: decoding the ids gives back every byte of the text (src/model.rs:146-160, checked
     chunk by chunk), a second pass and a pass over the two halves of the batch give the same ids (samples are
     independent, src/tokenizer.rs:107-110), and the first 8 MiB agree with the CPU oracle bit for bit."""
-    vflat, _ = synth.make_corpus(4 << 20, "mixed", seed_offset=0)
-    toks, scores = synth.build_vocab(vflat[: 2 << 20], 32000, 16)
+    toks, scores, _ = synth.load_spec_vocab(32000)   # SURVEY.md 8(d): the committed 64 MiB-slice vocabulary (bench.py's)
     flat, offs = synth.make_corpus(1024 << 20, "mixed", seed_offset=1000)
     nat = tgx.NativeModel(toks, scores)
     corpus = tgx.NativeCorpus(flat, offs)
@@ -519,3 +543,32 @@ def test_host_to_host_entry_point_chunks_and_errors(monkeypatch):
     assert str(e.value) == "no path to position 3/3" and e.value.sample == 2
     ids, oo = nat.encode_batch_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     assert ids.size == 0 and oo.tolist() == [0]
+
+
+def test_one_process_several_device_handles():
+    """tgx_encode_batch_multi: one batch from ONE host process over several model handles (one per GPU on a node; two
+    and three handles on the test box's one GPU here): byte-balanced shards, a host thread per handle, ids and offsets
+    packed in sample order — equal to the single call's; the lowest failing sample is reported across shards."""
+    flat, offs, toks, scores = corpus_and_vocab(8 << 20, "mixed", 6000, 16, seed_offset=17)
+    nat, ora = _pair(toks, scores)
+    want_ids, want_oo = ora.encode_batch_flat(flat, offs, threads=8)
+    for n in (1, 2, 3):
+        models = [nat] + [tgx.NativeModel(toks, scores) for _ in range(n - 1)]
+        ids, oo = tgx.NativeModel.encode_batch_multi(models, flat, offs)
+        np.testing.assert_array_equal(oo, want_oo)
+        np.testing.assert_array_equal(ids, want_ids)
+        for m in models[1:]:
+            m.free()
+    # more handles than samples, empty samples, an empty batch
+    f2, o2 = tgx.pack([b"ab", b"", b"c"])
+    small = tgx.NativeModel([b"a", b"b", b"c", b"ab"], [-1.0, -1.0, -1.0, -1.5])
+    ms = [small] + [tgx.NativeModel([b"a", b"b", b"c", b"ab"], [-1.0, -1.0, -1.0, -1.5]) for _ in range(4)]
+    ids, oo = tgx.NativeModel.encode_batch_multi(ms, f2, o2)
+    assert ids.tolist() == [3, 2] and oo.tolist() == [0, 1, 1, 2]
+    ids, oo = tgx.NativeModel.encode_batch_multi(ms, np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert ids.size == 0 and oo.tolist() == [0]
+    # NoPath in the second shard: the batch's sample index
+    f3, o3 = tgx.pack([b"ab" * 50, b"abc" * 10, b"ab" * 50, b"a" * 20 + b"x", b"b" * 90])
+    with pytest.raises(tgx.TokenGeeXError) as e:
+        tgx.NativeModel.encode_batch_multi(ms[:2], f3, o3)
+    assert e.value.status == 4 and e.value.sample == 3

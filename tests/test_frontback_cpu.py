@@ -109,3 +109,37 @@ def test_tokengeex_import_alias_has_the_stubs_surface():
     tk = tokengeex.Tokenizer.from_str('{"version":"2.0","special_tokens":["<EOS>"],"processors":[{"type":"crlf"}],'
                                       '"vocab":[{"value":"a","score":-1.0},{"value":"b","score":-2.0,"keep":true}]}')
     assert tk.vocab_size() == 3 and tk.decode([0, 1, 2], True) == "ab<EOS>" and tk.base_token_to_id(b"b") == 1
+
+
+def test_native_ends_of_the_list_surface():
+    """csrc/pyfast.c: pack_strs == the samples' str.encode("utf-8") back to back (1-, 2- and 4-byte string kinds, empty
+    samples, thread slices), with str.encode's error for a lone surrogate; rows_from_flat == the per-sample lists, with
+    and without the shared-int cache, ids beyond the cache as fresh ints."""
+    from tokengeex_amd import _tgxfast
+    rng = np.random.default_rng(3)
+    alphabet = ["a", "Z", " ", "\n", "é", "ß", "中", "文", "，", "😀", "\U0001F600", "\x00", "\x7f", "\x80", "߿", "ࠀ", "￿"]
+    texts = ["".join(rng.choice(alphabet, size=int(n))) for n in rng.integers(0, 200, size=3000)] + ["", "x" * 100000, "中" * 50000]
+    for threads in (1, 3, 8):
+        tb, ob = _tgxfast.pack_strs(texts, threads)
+        want = [t.encode("utf-8") for t in texts]
+        assert tb == b"".join(want)
+        assert np.frombuffer(ob, np.uint64).tolist() == np.concatenate([[0], np.cumsum([len(w) for w in want])]).tolist()
+    assert _tgxfast.pack_strs([]) == (b"", (0).to_bytes(8, "little"))
+    assert _tgxfast.pack_strs(("ab", "c")) [0] == b"abc"          # any sequence
+    with pytest.raises(UnicodeEncodeError):
+        _tgxfast.pack_strs(["fine", "bad \ud800 surrogate"])
+    with pytest.raises(TypeError):
+        _tgxfast.pack_strs(["fine", b"bytes"])
+    ids = rng.integers(0, 5000, size=20000).astype(np.uint32)
+    cuts = np.sort(rng.integers(0, ids.size + 1, size=300))
+    offs = np.concatenate([[0], cuts, [ids.size]]).astype(np.uint64)
+    want = [ids[int(offs[i]):int(offs[i + 1])].tolist() for i in range(offs.size - 1)]
+    cache = list(range(4000))                                      # ids 4000 .. 4999 lie beyond it
+    assert _tgxfast.rows_from_flat(ids, offs, cache) == want
+    assert _tgxfast.rows_from_flat(ids, offs, None) == want
+    rows = _tgxfast.rows_from_flat(ids, offs, cache)
+    k = int(np.flatnonzero(ids < 4000)[0]); r = int(np.searchsorted(offs, k, side="right") - 1)
+    assert rows[r][k - int(offs[r])] is cache[int(ids[k])]         # the shared object
+    assert _tgxfast.rows_from_flat(np.zeros(0, np.uint32), np.zeros(1, np.uint64), None) == []
+    with pytest.raises(ValueError):
+        _tgxfast.rows_from_flat(ids, np.array([0, ids.size + 1], np.uint64), None)

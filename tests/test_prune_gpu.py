@@ -52,8 +52,12 @@ def test_prune_end_to_end_matches_oracle_loop(dropout):
         assert gd[k][2] == wd[k][2]
         assert abs(gd[k][1] - wd[k][1]) <= 1e-7 * abs(wd[k][1]) + 1e-9, k
     assert np.all(np.diff([t[1] for t in got]) <= 0)
-    moved = sum(1 for a, b in zip(got, want) if a[0] != b[0])
-    assert moved <= len(got) // 10  # only near-tie neighbours may swap
+    # positions may differ only between tokens whose scores tie to the E-step tolerance: wherever the two orders
+    # disagree, the token the oracle has there and the token the GPU path has there have (oracle) scores within 1e-7
+    ws = {t[0]: t[1] for t in want}
+    for a, b in zip(got, want):
+        if a[0] != b[0]:
+            assert abs(ws[a[0]] - b[1]) <= 1e-7 * abs(b[1]) + 1e-9, (a, b)
     assert len(pruner.timings) >= 2 and all(r["to"] < r["from"] for r in pruner.timings)
 
 

@@ -48,6 +48,7 @@ SYMBOLS = {
     "tgx_dropout_u01_host": (_d, [_u64, _u64, _u64, _u32]),
     "tgx_encode_batch": (_i, [_vp, _vp, _vp, _u64, _d, _u64, _pvp]),
     "tgx_encode_batch_host": (_i, [_vp, _vp, _vp, _u64, _d, _u64, _vp, _u64, _vp, _pu64]),
+    "tgx_encode_batch_multi": (_i, [_vp, _u32, _vp, _vp, _u64, _d, _u64, _vp, _u64, _vp, _pu64]),
     "tgx_result_num_samples": (_u64, [_vp]),
     "tgx_result_num_tokens": (_u64, [_vp]),
     "tgx_result_ids": (_vp, [_vp]),
@@ -475,6 +476,21 @@ class NativeModel:
         t = C.c_uint64()
         check(lib.tgx_encode_batch_host(self._h, ptr(flat) if flat.size else None, ptr(offs), n, float(dropout),
                                         seed & (2**64 - 1), ptr(ids_out), ids_out.size, ptr(out_offs), C.byref(t)))
+        return ids_out[: t.value], out_offs
+
+    @staticmethod
+    def encode_batch_multi(models: "list[NativeModel]", flat: np.ndarray, offs: np.ndarray, dropout: float = 0.0, seed: int = 0):
+        """One batch over several model handles — one per GPU — from this one process (tgx_encode_batch_multi): byte-balanced
+        shards, a host thread per handle, ids and offsets packed in sample order -> (ids uint32[T], offsets uint64[S+1])."""
+        flat = np.ascontiguousarray(flat, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        n = offs.shape[0] - 1
+        ids_out = np.empty(max(1, int(offs[-1] - offs[0])), np.uint32)
+        out_offs = np.zeros(n + 1, np.uint64)
+        handles = (C.c_void_p * len(models))(*[m._h for m in models])
+        t = C.c_uint64()
+        check(lib.tgx_encode_batch_multi(handles, len(models), ptr(flat) if flat.size else None, ptr(offs), n, float(dropout),
+                                         seed & (2**64 - 1), ptr(ids_out), ids_out.size, ptr(out_offs), C.byref(t)))
         return ids_out[: t.value], out_offs
 
     def prune_alternatives(self) -> tuple[np.ndarray, np.ndarray, np.ndarray]:

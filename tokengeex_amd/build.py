@@ -48,11 +48,27 @@ def build_synth(force: bool = False) -> str:
     return SYNTH_OUT
 
 
+FAST_OUT = os.path.join(HERE, "_tgxfast.so")
+
+
+def build_pyfast(force: bool = False) -> str:
+    """The native ends of the list[str] -> list[list[int]] surface (csrc/pyfast.c: CPython C API, gcc, no GPU code)."""
+    import sysconfig
+    src = os.path.join(CSRC, "pyfast.c")
+    if not force and os.path.exists(FAST_OUT) and os.path.getmtime(FAST_OUT) >= os.path.getmtime(src):
+        return FAST_OUT
+    inc = sysconfig.get_paths()["include"]
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-pthread", "-I", inc, "-o", FAST_OUT + ".tmp", src])
+    os.replace(FAST_OUT + ".tmp", FAST_OUT)
+    return FAST_OUT
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compiles every source that is newer than its object (or whose headers are) with hipcc, in parallel, into
     csrc/build/ (git-ignored), then links tokengeex_amd/libtgx.so."""
     from concurrent.futures import ThreadPoolExecutor
     build_synth(force)
+    build_pyfast(force)
     if not force and not needs_build():
         return OUT
     objdir = os.path.join(CSRC, "build")

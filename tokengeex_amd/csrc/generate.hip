@@ -224,7 +224,9 @@ static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_
         owned.push_back(p);
         return p;
     };
-    const bool dbg = getenv("TGX_DEBUG") != nullptr;
+    // (TGX_DEBUG as tgx_api.cpp reads it: set, not empty, not "0")
+    const char* dbg_env = getenv("TGX_DEBUG");
+    const bool dbg = dbg_env && *dbg_env && *dbg_env != '0';
 #define G_TRY(expr)                                                       \
     do {                                                                  \
         if (dbg) { fprintf(stderr, "[tgx] generate: %s\n", #expr); fflush(stderr); } \

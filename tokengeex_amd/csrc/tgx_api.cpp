@@ -1795,6 +1795,78 @@ tgx_status tgx_encode_batch_host(tgx_model* m, const uint8_t* text, const uint64
     return TGX_OK;
 }
 
+// One host process, several devices: the batch is cut at sample boundaries into one byte-balanced shard per model
+// handle (one handle per GPU; the reference's batch is ONE call from one process, src/tokenizer.rs:102-111), every shard
+// goes through tgx_encode_batch_host on a host thread of its own, and the shards' ids are packed in sample order.  No
+// collective: the path shards by samples.  ids_out must hold one id per input byte (ids_cap >= bytes: every shard writes
+// at its text offset first).  With dropout the keep decisions hash the sample's index in its SHARD.
+tgx_status tgx_encode_batch_multi(tgx_model* const* models, uint32_t n_models, const uint8_t* text, const uint64_t* offs,
+                                  uint64_t n_samples, double dropout, uint64_t seed, uint32_t* ids_out, uint64_t ids_cap,
+                                  uint64_t* offs_out, uint64_t* n_tokens) {
+    if (!models || n_models == 0 || !offs_out || !n_tokens || (n_samples && !offs)) return fail(TGX_ERR_INVALID, "tgx_encode_batch_multi: NULL argument");
+    for (uint32_t k = 0; k < n_models; k++)
+        if (!models[k]) return fail(TGX_ERR_INVALID, "tgx_encode_batch_multi: NULL model handle");
+    *n_tokens = 0;
+    offs_out[0] = 0;
+    if (n_samples == 0) return TGX_OK;
+    const uint64_t N = offs[n_samples] - offs[0];
+    if (ids_cap < N) return fail(TGX_ERR_INVALID, "tgx_encode_batch_multi: ids_out must hold one id per input byte (%llu), it holds %llu",
+                                 (unsigned long long)N, (unsigned long long)ids_cap);
+    // shard bounds: the first sample whose start is at or beyond k / n_models of the bytes
+    std::vector<uint64_t> cut(n_models + 1, n_samples);
+    cut[0] = 0;
+    for (uint32_t k = 1; k < n_models; k++) {
+        const uint64_t want = offs[0] + N / n_models * k;
+        cut[k] = (uint64_t)(std::lower_bound(offs, offs + n_samples, want) - offs);
+        cut[k] = std::max(cut[k], cut[k - 1]);
+    }
+    struct Shard {
+        tgx_status st = TGX_OK;
+        uint64_t tokens = 0;
+        std::string msg;
+        uint64_t es = 0, ep = 0, el = 0;
+        std::vector<uint64_t> lo;
+    };
+    std::vector<Shard> sh(n_models);
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < n_models; k++) {
+        th.emplace_back([&, k]() {
+            Shard& S = sh[k];
+            const uint64_t a = cut[k], b = cut[k + 1];
+            if (b == a) return;
+            S.lo.assign(b - a + 1, 0);
+            const uint64_t region = offs[a] - offs[0];  // (at most one token per byte: the shard's ids fit behind its text offset)
+            S.st = tgx_encode_batch_host(models[k], text, offs + a, b - a, dropout, seed, ids_out + region, ids_cap - region, S.lo.data(), &S.tokens);
+            if (S.st != TGX_OK) {  // the error state is this thread's
+                S.msg = g_err_msg;
+                S.es = g_err_sample + a;
+                S.ep = g_err_pos;
+                S.el = g_err_len;
+            }
+        });
+    }
+    for (std::thread& t : th) t.join();
+    for (uint32_t k = 0; k < n_models; k++)
+        if (sh[k].st != TGX_OK) {  // the lowest failing shard: the lowest failing sample of the batch
+            g_err_msg = sh[k].msg;
+            g_err_sample = sh[k].es;
+            g_err_pos = sh[k].ep;
+            g_err_len = sh[k].el;
+            return sh[k].st;
+        }
+    uint64_t base = 0;
+    for (uint32_t k = 0; k < n_models; k++) {
+        const uint64_t a = cut[k], b = cut[k + 1];
+        if (b == a) continue;
+        const uint64_t region = offs[a] - offs[0];
+        if (region != base && sh[k].tokens) memmove(ids_out + base, ids_out + region, sh[k].tokens * sizeof(uint32_t));
+        for (uint64_t i = 0; i <= b - a; i++) offs_out[a + i] = base + sh[k].lo[i];
+        base += sh[k].tokens;
+    }
+    *n_tokens = base;
+    return TGX_OK;
+}
+
 uint64_t tgx_result_num_samples(const tgx_result* r) { return r ? r->n_samples : 0; }
 uint64_t tgx_result_num_tokens(const tgx_result* r) { return r ? r->n_tokens : 0; }
 

@@ -16,6 +16,7 @@ import unicodedata
 import numpy as np
 
 from . import _lib
+from . import _tgxfast as _fast  # csrc/pyfast.c, built by tokengeex_amd/build.py beside libtgx.so
 from ._lib import TokenGeeXError
 
 SERIALIZATION_VERSION = "2.0"  # src/tokenizer.rs:347
@@ -147,10 +148,22 @@ class Tokenizer:
         normalisation form (unicodedata) keeps the per-segment Python path."""
         return all(isinstance(p, CrlfProcessor) for p in self._processors)
 
+    def _rows_native(self, texts: list[str], dropout: float, ordinary: bool) -> list[list[int]]:
+        """list[str] -> list[list[int]] with both ends in native code (csrc/pyfast.c; bindings/python/src/lib.rs:51-69 builds
+        the same shapes in Rust): the samples' UTF-8 packed by host threads straight from the strings, the rows built from
+        shared int objects (one per id, made once per tokenizer) — no bytes object per sample, no int object per token."""
+        text_b, offs_b = _fast.pack_strs(texts)
+        flat = np.frombuffer(text_b, dtype=np.uint8)
+        offs = np.frombuffer(offs_b, dtype=np.uint64)
+        ids, o = self.encode_batch_flat(flat, offs, dropout, ordinary=ordinary)
+        n_ids = self.vocab_size()
+        if getattr(self, "_int_cache", None) is None or len(self._int_cache) != n_ids:
+            self._int_cache = list(range(n_ids))
+        return _fast.rows_from_flat(np.ascontiguousarray(ids, np.uint32), np.ascontiguousarray(o, np.uint64), self._int_cache)
+
     def encode_ordinary_batch(self, texts: list[str], dropout: float) -> list[list[int]]:
         if self._native_front():
-            ids, offs = self.encode_batch_flat(*_lib.pack([t.encode("utf-8") for t in texts]), dropout, ordinary=True)
-            return _split_rows(ids, offs)
+            return self._rows_native(texts, dropout, True)
         segs = [self._preprocess(t).encode("utf-8") for t in texts]
         ids, offs = self._encode_segments(segs, dropout)
         return [ids[int(offs[i]):int(offs[i + 1])].tolist() for i in range(len(texts))]
@@ -182,8 +195,7 @@ class Tokenizer:
         if not self._special_tokens:
             return self.encode_ordinary_batch(texts, dropout)
         if self._native_front():
-            ids, offs = self.encode_batch_flat(*_lib.pack([t.encode("utf-8") for t in texts]), dropout)
-            return _split_rows(ids, offs)
+            return self._rows_native(texts, dropout, False)
         base = self.base_vocab_size()
         plan, segs = [], []  # per text: list of (special id | -1)
         for t in texts:
