@@ -127,12 +127,14 @@ uint64_t tgx_utf8_lossy(const uint8_t *s, uint64_t n, uint8_t *out);
 
 /* ---- `generate`: document frequencies of substrings on the device (csrc/generate.hip) ----------------
  * VocabularyGenerator::feed (src/generate.rs:54-139): in how many samples does every char-aligned substring of
- * at most max_token_length (<= 16) bytes occur?  Parts are the byte ranges the windows may lie in (the samples,
+ * at most max_token_length (<= 32) bytes occur?  Parts are the byte ranges the windows may lie in (the samples,
  * or the matches of the split regex), sorted, disjoint, with ascending sample ids.  A (sample, substring) pair is
  * kept iff tgx_generate_u01(seed, sample, FNV-1a-64(substring)) < insert_probability (the reference draws from an
  * unseeded thread RNG).  Out: one entry per distinct substring — position and length of one occurrence, number
- * of samples — malloc'd (tgx_free).  Fails with TGX_ERR_UNSUPPORTED when two different substrings share a
- * 64-bit hash (detected by comparing bytes; *n_collisions says how many entries). */
+ * of samples — malloc'd (tgx_free).  Two different substrings in one 64-bit sort key are detected (every entry of a run is
+ * compared with the run's first, byte by byte) and resolved: the pass is sorted again under a second, independent hash of
+ * the windows' bytes (up to three times; *n_collisions = entries that had met a foreign run in the discarded attempts).
+ * More than 2^32 - 1 kept windows in one call: TGX_ERR_UNSUPPORTED ("feed smaller batches"). */
 tgx_status tgx_substring_df(int device, const uint8_t *text, uint64_t n_bytes, const uint64_t *part_begin,
                             const uint64_t *part_end, const uint32_t *part_sample, uint64_t n_parts,
                             uint32_t max_token_length, double insert_probability, uint64_t seed,

@@ -53,3 +53,16 @@ def test_keep_rule_is_the_librarys():
     assert fnv1a64(b"") == 0xCBF29CE484222325 and fnv1a64(b"a") == 0xAF63DC4C8601EC8C   # FNV-1a test vectors
     for seed, sample, tok in [(0, 0, "a"), (7, 123456, "hello"), (2**63 + 5, 99, "中文"), (1, 2**26, " x")]:
         assert keep_u01(seed, sample, tok) == _lib.generate_u01(seed, sample, fnv1a64(tok.encode()))
+
+
+def test_pass_sizing_keeps_a_device_pass_below_its_window_limit():
+    """tokengeex_amd/generate.py: pass_bytes — tgx_substring_df takes fewer than 2^32 kept windows per call, and a byte
+    position of ASCII text starts max_token_length of them: the text of one pass is sized by ENCODED bytes accordingly."""
+    import importlib.util
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tokengeex_amd", "generate.py")).read()
+    ns = {}
+    exec(src[src.index("def pass_bytes"):src.index("def _fnv1a64")], ns)   # (importing the package needs the built library)
+    for mtl in (1, 8, 16, 24, 32):
+        b = ns["pass_bytes"](mtl)
+        assert b * mtl < (1 << 32) and b <= (256 << 20) and b >= (64 << 20)

@@ -74,8 +74,8 @@ def test_top_k_leaves_the_vocabulary_exact_or_refuses():
         dev2.generate(4000)
     # several device passes (forced: 64 KiB of text per pass): frequencies add, every pass reports what it cut off
     import tokengeex_amd.generate as gen_mod
-    old = gen_mod._PASS_BYTES
-    gen_mod._PASS_BYTES = 64 << 10
+    old = gen_mod.pass_bytes
+    gen_mod.pass_bytes = lambda mtl: 64 << 10
     try:
         dev3, _ = _both(samples, 16, 1.0, None, ALLOW, ["std::"], ["    "], top_k=1000000)   # nothing is cut in a 64 KiB pass
         assert dev3.generate(1500) == ora.generate(1500) and dev3.passes > 4
@@ -87,7 +87,36 @@ def test_top_k_leaves_the_vocabulary_exact_or_refuses():
         except tgx.TokenGeeXError as e:
             assert "top_k too small" in str(e)
     finally:
-        gen_mod._PASS_BYTES = old
+        gen_mod.pass_bytes = old
+
+
+@pytest.mark.parametrize("mtl", [20, 24, 32])
+def test_windows_of_up_to_32_bytes(mtl):
+    """max_token_length beyond 16 (the reference's CLI default is 24, src/cli.rs:675; src/generate.rs:78-83 has no limit):
+    frequencies and vocabulary equal to the oracle's, with multi-byte characters that end exactly at the limit."""
+    samples = _samples(96 << 10, seed_offset=9) + ["中文字符" * 12, "x" * 70, "é" * 40, "ab" * 33, "𝒳" * 9]
+    dev, ora = _both(samples, mtl, 1.0, None, None)
+    assert dev.frequencies == ora.frequencies
+    assert max(len(k.encode("utf-8")) for k in dev.frequencies) == mtl
+    dev, ora = _both(samples, mtl, 0.3, None, ALLOW, ["std::"], ["    "], chunks=2, seed=4)
+    assert dev.frequencies == ora.frequencies and dev.generate(2000) == ora.generate(2000)
+
+
+def test_key_collisions_are_resolved(monkeypatch):
+    """Two different substrings in one sort key: every entry of a run is compared with the run's first, byte by byte,
+    and a pass with any such entry is sorted again under a second, independent hash.  Forced here by keeping 12 bits
+    of the first attempt's keys (TGX_GENERATE_COLLIDE): the counts are the oracle's all the same, and the call reports
+    how many entries had met a foreign run."""
+    monkeypatch.setenv("TGX_GENERATE_COLLIDE", "12")
+    samples = _samples(64 << 10, seed_offset=3) + ["中文中文", "abcabc"]
+    dev, ora = _both(samples, 12, 1.0, None, None)
+    assert dev.frequencies == ora.frequencies and len(dev.frequencies) > 10000
+    flat, offs = _lib.pack([b"abab", b"ab", b"", b"xyz"])
+    keep = np.flatnonzero(offs[1:] > offs[:-1])
+    monkeypatch.setenv("TGX_GENERATE_COLLIDE", "2")
+    pos, ln, df, n_windows, collisions = _lib.substring_df(flat, offs[:-1][keep], offs[1:][keep], keep.astype(np.uint32), 4, with_collisions=True)
+    got = {flat[int(p):int(p + l)].tobytes(): int(d) for p, l, d in zip(pos, ln, df)}
+    assert got[b"ab"] == 2 and got[b"abab"] == 1 and len(got) == 13 and collisions > 0
 
 
 def test_substring_df_raw_interface():
@@ -99,7 +128,7 @@ def test_substring_df_raw_interface():
                    b"xy": 1, b"yz": 1, b"xyz": 1}
     assert n_windows == 10 + 3 + 6
     with pytest.raises(Exception):
-        _lib.substring_df(flat, offs[:-1][keep], offs[1:][keep], keep.astype(np.uint32), 17)
+        _lib.substring_df(flat, offs[:-1][keep], offs[1:][keep], keep.astype(np.uint32), 33)
     # top 3: the three substrings that occur in two samples, and the cut-off frequency 1
     pos, ln, df, _, n_distinct, cut = _lib.substring_df_top(flat, offs[:-1][keep], offs[1:][keep], keep.astype(np.uint32), 4, 3)
     assert {flat[int(p):int(p + l)].tobytes() for p, l in zip(pos, ln)} == {b"a", b"b", b"ab"} and df.tolist() == [2, 2, 2]

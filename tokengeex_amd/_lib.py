@@ -285,8 +285,9 @@ def decode_batch_flat(vocab_flat, vocab_offs, vocab_size: int, special_flat, spe
 
 
 def substring_df(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray, part_sample: np.ndarray,
-                 max_token_length: int, insert_probability: float = 1.0, seed: int = 0, device: int = 0):
-    """Document frequencies of char-aligned substrings on the device -> (pos u64[D], len u32[D], df u32[D], n_windows)."""
+                 max_token_length: int, insert_probability: float = 1.0, seed: int = 0, device: int = 0, with_collisions: bool = False):
+    """Document frequencies of char-aligned substrings on the device -> (pos u64[D], len u32[D], df u32[D], n_windows
+    [, entries that met a foreign run in a discarded attempt])."""
     flat = np.ascontiguousarray(flat, np.uint8)
     pb, pe = np.ascontiguousarray(part_begin, np.uint64), np.ascontiguousarray(part_end, np.uint64)
     ps = np.ascontiguousarray(part_sample, np.uint32)
@@ -295,7 +296,8 @@ def substring_df(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray,
                                max_token_length, float(insert_probability), seed & (2**64 - 1), C.byref(pos), C.byref(ln),
                                C.byref(df), C.byref(n), C.byref(nw), C.byref(nc)))
     k = n.value
-    return _take(pos, k, C.c_uint64, np.uint64), _take(ln, k, C.c_uint32, np.uint32), _take(df, k, C.c_uint32, np.uint32), nw.value
+    out = (_take(pos, k, C.c_uint64, np.uint64), _take(ln, k, C.c_uint32, np.uint32), _take(df, k, C.c_uint32, np.uint32), nw.value)
+    return out + (nc.value,) if with_collisions else out
 
 
 def substring_df_top(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray, part_sample: np.ndarray,

@@ -61,6 +61,9 @@ struct WindowParams {
     uint32_t max_len;
     double prob;
     uint64_t seed;
+    uint64_t salt;                // 0: the sort key is the window's FNV-1a hash; else a second, salted hash of its bytes (the retry
+                                  // after two different substrings met in one key)
+    uint64_t key_mask;            // ~0; fewer bits only in the forced-collision test
     uint32_t* blk_count;          // pass 1: kept windows per block
     const uint64_t* blk_offs;     // pass 2: exclusive scan of blk_count
     uint64_t* keys;               // pass 2: window hash
@@ -85,12 +88,14 @@ __global__ __launch_bounds__(256) void window_kernel(WindowParams P) {
     // the windows of this position in ascending length; `emit` is called for the kept ones (src/generate.rs:99-120)
     auto windows = [&](auto emit) {
         uint32_t kept = 0;
-        uint64_t h = kFnvOffset;
+        uint64_t h = kFnvOffset, g = kFnvOffset ^ P.salt;
         for (uint32_t len = 1; len <= P.max_len && p + len <= end; ++len) {
-            h = (h ^ (uint64_t)P.text[p + len - 1]) * kFnvPrime;
+            const uint64_t c = (uint64_t)P.text[p + len - 1];
+            h = (h ^ c) * kFnvPrime;
+            if (P.salt) g = ((g ^ c) * 0x9E3779B97F4A7C15ULL) ^ (g >> 29);  // an unrelated mixing chain: keys that met under h part here
             const bool boundary = (p + len == end) || (P.text[p + len] & 0xC0u) != 0x80u;
-            if (boundary && (P.prob >= 1.0 || generate_u01(P.seed, sample, h) < P.prob)) {
-                emit(kept, h, len);
+            if (boundary && (P.prob >= 1.0 || generate_u01(P.seed, sample, h) < P.prob)) {  // (the keep rule always hashes h)
+                emit(kept, (P.salt ? g : h) & P.key_mask, len);
                 kept++;
             }
         }
@@ -177,12 +182,14 @@ extern "C" {
 
 double tgx_generate_u01(uint64_t seed, uint64_t sample, uint64_t window_hash) { return tgx::generate_u01(seed, sample, window_hash); }
 
-// Document frequencies of the char-aligned substrings of at most max_token_length (<= 16) bytes of the parts
+// Document frequencies of the char-aligned substrings of at most max_token_length (<= 32) bytes of the parts
 // text[part_begin[k], part_end[k]) (sorted, disjoint; part_sample[k] non-decreasing), kept with probability
 // insert_probability per (sample, substring).  Out: one entry per distinct substring — the position and length
 // of one occurrence and the number of samples it occurs in — malloc'd (tgx_free), in ascending order of the
-// substrings' FNV-1a hashes.  *n_collisions > 0 (two different substrings with one 64-bit hash) makes the
-// call fail with TGX_ERR_UNSUPPORTED: callers fall back to the host path.  text must be < 4 GiB.
+// substrings' sort keys (their FNV-1a hashes).  Two different substrings with one 64-bit key are DETECTED (every entry of
+// a run is compared with the run's first, byte by byte) and resolved: the pass is sorted again under a second, salted hash
+// of the windows' bytes, up to three times; *n_collisions reports how many entries met a foreign run in the attempts that
+// were discarded.  text must be < 4 GiB.
 static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
                                     const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
                                     uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t top_k,
@@ -199,7 +206,8 @@ static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_
     if (n_windows) *n_windows = 0;
     if (n_collisions) *n_collisions = 0;
     if (n_parts && (!text || !part_begin || !part_end || !part_sample)) return tgx_set_error(TGX_ERR_INVALID, "tgx_substring_df: NULL argument");
-    if (max_token_length < 1 || max_token_length > 16) return tgx_set_error(TGX_ERR_UNSUPPORTED, "tgx_substring_df: max_token_length must be 1..16");
+    // (windows of up to 32 bytes: the reference's CLI default is 24, src/cli.rs:675; a value carries length - 1 in 5 bits)
+    if (max_token_length < 1 || max_token_length > 32) return tgx_set_error(TGX_ERR_UNSUPPORTED, "tgx_substring_df: max_token_length must be 1..32");
     if (n_bytes >= (1ull << 32)) return tgx_set_error(TGX_ERR_UNSUPPORTED, "tgx_substring_df: feed at most 4 GiB per call");
     if (n_parts == 0 || n_bytes == 0) return TGX_OK;
     for (uint64_t k = 0; k < n_parts; k++) {
@@ -301,53 +309,62 @@ static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_
     P.blk_offs = d_bo;
     P.keys = d_keys;
     P.vals = d_vals;
-    hipLaunchKernelGGL(window_kernel<true>, dim3((uint32_t)n_blocks), dim3(256), 0, 0, P);
-    G_TRY(hipGetLastError());
+    // forced-collision test (TGX_KNOBS=1 TGX_GENERATE_COLLIDE=bits): the first attempt keeps that many key bits only
+    uint64_t first_mask = ~0ull;
     {
-        size_t tb = 0;
-        G_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, (size_t)M));
-        void* tmp = dalloc(tb);
-        if (!tmp) return fail(TGX_ERR_DEVICE, "out of device memory (generate: sort)");
-        G_TRY(rocprim::radix_sort_pairs(tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (size_t)M));
+        const char* kn = getenv("TGX_KNOBS");
+        const char* fc = (kn && *kn && *kn != '0') ? getenv("TGX_GENERATE_COLLIDE") : nullptr;
+        if (fc && atoi(fc) > 0 && atoi(fc) < 64) first_mask = (1ull << atoi(fc)) - 1ull;
     }
-    // run ids: inclusive scan of the run heads (the unsorted key buffer is free now)
-    uint32_t* d_head = reinterpret_cast<uint32_t*>(d_keys);
+    uint32_t* d_head = reinterpret_cast<uint32_t*>(d_keys);  // (the unsorted key buffer is free once the sort is done)
     uint32_t* d_run = reinterpret_cast<uint32_t*>(d_keys) + M;
     const uint32_t mblocks = (uint32_t)((M + 255) / 256);
-    hipLaunchKernelGGL(run_heads_kernel, dim3(mblocks), dim3(256), 0, 0, d_keys2, M, d_head);
-    G_TRY(hipGetLastError());
-    {
-        size_t tb = 0;
-        G_TRY((rocprim::inclusive_scan(nullptr, tb, d_head, d_run, (size_t)M, rocprim::plus<uint32_t>())));
-        void* tmp = dalloc(tb);
-        if (!tmp) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
-        G_TRY((rocprim::inclusive_scan(tmp, tb, d_head, d_run, (size_t)M, rocprim::plus<uint32_t>())));
-    }
+    uint64_t* d_rep = d_vals;  // the unsorted values are free after the sort: n_runs <= M
+    uint32_t* d_df = nullptr;
     uint32_t n_runs = 0;
-    G_TRY(hipMemcpy(&n_runs, d_run + (M - 1), 4, hipMemcpyDeviceToHost));
-    if (dbg) {
-        std::vector<uint32_t> hh(2 * M);
-        (void)hipMemcpy(hh.data(), d_head, 2 * M * 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[tgx] generate: M=%llu n_runs=%u heads:", (unsigned long long)M, n_runs);
-        for (uint64_t i = 0; i < std::min<uint64_t>(M, 24); i++) fprintf(stderr, " %u/%u", hh[i], hh[M + i]);
-        fprintf(stderr, "\n[tgx] generate: d_keys=%p d_vals=%p d_keys2=%p d_vals2=%p d_head=%p d_run=%p\n", (void*)d_keys, (void*)d_vals,
-                (void*)d_keys2, (void*)d_vals2, (void*)d_head, (void*)d_run);
+    unsigned long long coll_total = 0, coll = 0;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        P.salt = attempt ? 0xD6E8FEB86659FD93ULL * (uint64_t)attempt : 0ull;
+        P.key_mask = attempt ? ~0ull : first_mask;
+        G_TRY(hipMemset(d_ctr, 0, 64));
+        hipLaunchKernelGGL(window_kernel<true>, dim3((uint32_t)n_blocks), dim3(256), 0, 0, P);
+        G_TRY(hipGetLastError());
+        {
+            size_t tb = 0;
+            G_TRY(rocprim::radix_sort_pairs(nullptr, tb, d_keys, d_keys2, d_vals, d_vals2, (size_t)M));
+            void* tmp = dalloc(tb);
+            if (!tmp) return fail(TGX_ERR_DEVICE, "out of device memory (generate: sort)");
+            G_TRY(rocprim::radix_sort_pairs(tmp, tb, d_keys, d_keys2, d_vals, d_vals2, (size_t)M));
+        }
+        // run ids: inclusive scan of the run heads
+        hipLaunchKernelGGL(run_heads_kernel, dim3(mblocks), dim3(256), 0, 0, d_keys2, M, d_head);
+        G_TRY(hipGetLastError());
+        {
+            size_t tb = 0;
+            G_TRY((rocprim::inclusive_scan(nullptr, tb, d_head, d_run, (size_t)M, rocprim::plus<uint32_t>())));
+            void* tmp = dalloc(tb);
+            if (!tmp) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
+            G_TRY((rocprim::inclusive_scan(tmp, tb, d_head, d_run, (size_t)M, rocprim::plus<uint32_t>())));
+        }
+        G_TRY(hipMemcpy(&n_runs, d_run + (M - 1), 4, hipMemcpyDeviceToHost));
+        if (dbg) fprintf(stderr, "[tgx] generate: attempt %d M=%llu n_runs=%u\n", attempt, (unsigned long long)M, n_runs);
+        if (n_runs == 0 || n_runs > M) return fail(TGX_ERR_DEVICE, "tgx_substring_df: inconsistent run count");
+        d_df = (uint32_t*)dalloc((size_t)n_runs * 4);
+        if (!d_df) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
+        G_TRY(hipMemset(d_df, 0, (size_t)n_runs * 4));
+        hipLaunchKernelGGL(run_count_kernel, dim3(mblocks), dim3(256), 0, 0, d_keys2, d_vals2, d_run, M, n_runs, d_rep, d_df, d_ctr + 1);
+        G_TRY(hipGetLastError());
+        hipLaunchKernelGGL(run_check_kernel, dim3(mblocks), dim3(256), 0, 0, d_text, d_vals2, d_run, M, n_runs, d_rep, d_ctr, d_ctr + 1);
+        G_TRY(hipGetLastError());
+        unsigned long long ctr[2] = {0, 0};  // [0] entries that met a foreign run (a key collision), [1] entries whose run id was out of range
+        G_TRY(hipMemcpy(ctr, d_ctr, 16, hipMemcpyDeviceToHost));
+        if (ctr[1]) return fail(TGX_ERR_DEVICE, "tgx_substring_df: entries with a run id outside [1, n_runs] (run ids corrupt)");
+        coll = ctr[0];
+        coll_total += coll;
+        if (!coll) break;  // every run is one substring: the counts are exact
     }
-    if (n_runs == 0 || n_runs > M) return fail(TGX_ERR_DEVICE, "tgx_substring_df: inconsistent run count");
-    uint64_t* d_rep = d_vals;  // the unsorted values are free now: n_runs <= M
-    uint32_t* d_df = (uint32_t*)dalloc((size_t)n_runs * 4);
-    if (!d_df) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
-    G_TRY(hipMemset(d_df, 0, (size_t)n_runs * 4));
-    hipLaunchKernelGGL(run_count_kernel, dim3(mblocks), dim3(256), 0, 0, d_keys2, d_vals2, d_run, M, n_runs, d_rep, d_df, d_ctr + 1);
-    G_TRY(hipGetLastError());
-    hipLaunchKernelGGL(run_check_kernel, dim3(mblocks), dim3(256), 0, 0, d_text, d_vals2, d_run, M, n_runs, d_rep, d_ctr, d_ctr + 1);
-    G_TRY(hipGetLastError());
-    unsigned long long ctr[2] = {0, 0};  // [0] hash collisions, [1] entries whose run id was out of range
-    G_TRY(hipMemcpy(ctr, d_ctr, 16, hipMemcpyDeviceToHost));
-    if (ctr[1]) return fail(TGX_ERR_DEVICE, "tgx_substring_df: entries with a run id outside [1, n_runs] (run ids corrupt)");
-    const unsigned long long coll = ctr[0];
-    if (n_collisions) *n_collisions = coll;
-    if (coll) return fail(TGX_ERR_UNSUPPORTED, "tgx_substring_df: two different substrings share a 64-bit hash: use the host path for this batch");
+    if (n_collisions) *n_collisions = coll_total;
+    if (coll) return fail(TGX_ERR_UNSUPPORTED, "tgx_substring_df: different substrings shared a 64-bit key under four independent hashes");
     if (n_distinct) *n_distinct = n_runs;
     // top_k: only the top_k most frequent substrings leave the device (VocabularyGenerator::generate keeps the most
     // frequent ones, src/generate.rs:150-152, 199-213): a stable descending radix sort of (df, representative) —

@@ -252,6 +252,10 @@ static PyObject* rows_from_flat(PyObject* self, PyObject* args) {
             for (uint64_t k = a; k < b; k++) {
                 const uint32_t t = id[k];
                 PyObject* o;
+                if (k + 16 < T) {  /* the shared object's header (its reference count) 16 tokens ahead */
+                    const uint32_t tn = id[k + 16];
+                    if ((Py_ssize_t)tn < csize) __builtin_prefetch(citems[tn], 1, 1);
+                }
                 if ((Py_ssize_t)t < csize) {
                     o = citems[t];
                     Py_INCREF(o);

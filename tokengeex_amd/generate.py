@@ -6,7 +6,7 @@ initial vocabulary `prune` starts from.
 hashes its windows, a radix sort groups equal substrings, a run pass counts distinct samples; the split regex
 reaches the device as byte ranges, the allow regex — a pure function of the candidate — is applied on the host to
 the substrings that come back, and the added / suggested tokens are searched on the host as in the reference.
-There is no host fallback: without a GPU (or for max_token_length > 16) the calls fail.  The checker of this path
+There is no host fallback: without a GPU (or for max_token_length > 32) the calls fail.  The checker of this path
 is the CPU oracle's restatement of the generator (test infrastructure, never imported here).
 
 Round 3: `top_k`.  `generate(size)` keeps the most frequent substrings (src/generate.rs:150-152, 199-213), so only
@@ -35,7 +35,14 @@ from . import _lib
 from .merge import compile_rust_regex
 
 _M64 = (1 << 64) - 1
-_PASS_BYTES = 1 << 30  # text per device pass (tgx_substring_df takes < 4 GiB and < 2^32 kept windows)
+
+
+def pass_bytes(max_token_length: int) -> int:
+    """UTF-8 bytes of text per device pass: tgx_substring_df takes < 2^32 kept windows per call, a byte position starts at
+    most max_token_length of them (ASCII text, insert_probability 1; 10.5 per byte measured on the mixed bench corpus at 16),
+    and a window costs 32 bytes of device scratch.  256 MiB at most."""
+    return min(256 << 20, int(0.9 * (1 << 32)) // (int(max_token_length) + 2))
+
 
 
 def _fnv1a64(data: bytes) -> int:
@@ -57,8 +64,8 @@ class VocabularyGenerator:
                  added_tokens=(), suggested_tokens=(), seed: int = 0, device: int = 0, top_k: int | None = None):
         if device is None:
             raise _lib.TokenGeeXError("VocabularyGenerator counts on a GPU: there is no host path")
-        if int(max_token_length) > 16:
-            raise _lib.TokenGeeXError("VocabularyGenerator: max_token_length must be <= 16 (tgx_substring_df)")
+        if int(max_token_length) > 32:  # (the reference has no limit, src/generate.rs:78-83; its CLI's default is 24, src/cli.rs:675)
+            raise _lib.TokenGeeXError("VocabularyGenerator: max_token_length must be <= 32 (tgx_substring_df)")
         if _lib.device_count() <= int(device):
             raise _lib.TokenGeeXError("VocabularyGenerator: no usable HIP device (gfx950 required); there is no CPU fallback")
         self.device = int(device)
@@ -70,7 +77,9 @@ class VocabularyGenerator:
         self.seed = seed
         self.top_k = int(top_k) if top_k else 0
         self._fed = 0                       # samples seen (the keep rule hashes the global sample index)
-        self._pending: list[str] = []       # fed, not yet counted
+        self._pending: list[str] = []       # fed, not yet counted ...
+        self._pending_enc: list[bytes] = []  # ... and their UTF-8 (a pass is sized by ENCODED bytes)
+        self._pending_bytes = 0
         self._pending_first = 0
         self._freq: dict[str, int] = {}
         self._bound_seen: dict[str, int] = {}  # per substring: the cut-off bounds of the passes that DID return it
@@ -87,23 +96,38 @@ class VocabularyGenerator:
         The samples are counted by the next device pass (as many samples as fit one pass at a time)."""
         if not self._pending:
             self._pending_first = self._fed
+        enc = [s.encode("utf-8", "surrogatepass") for s in samples]
         self._pending.extend(samples)
+        self._pending_enc.extend(enc)
+        self._pending_bytes += sum(len(b) for b in enc)
         self._fed += len(samples)
-        if sum(len(s) for s in self._pending) >= _PASS_BYTES:
+        if self._pending_bytes >= pass_bytes(self.max_token_length):
             self._flush()
 
     def _flush(self) -> None:
+        limit = pass_bytes(self.max_token_length)
         while self._pending:
             n, size = 0, 0
-            while n < len(self._pending) and (n == 0 or size + len(self._pending[n]) <= _PASS_BYTES):
-                size += len(self._pending[n])
+            while n < len(self._pending) and (n == 0 or size + len(self._pending_enc[n]) <= limit):
+                size += len(self._pending_enc[n])
                 n += 1
-            self._count(self._pending[:n], self._pending_first)
-            self._pending = self._pending[n:]
+            self._count_split(self._pending[:n], self._pending_enc[:n], self._pending_first)
+            self._pending, self._pending_enc = self._pending[n:], self._pending_enc[n:]
+            self._pending_bytes -= size
             self._pending_first += n
 
-    def _count(self, samples: list[str], first: int) -> None:
-        enc = [s.encode("utf-8", "surrogatepass") for s in samples]
+    def _count_split(self, samples: list[str], enc: list[bytes], first: int) -> None:
+        """One device pass; a batch the device refuses for its size (more than 2^32 kept windows) is halved and retried."""
+        try:
+            self._count(samples, enc, first)
+        except _lib.TokenGeeXError as exc:
+            if exc.status != _lib.ERR_UNSUPPORTED or "windows" not in str(exc) or len(samples) < 2:
+                raise
+            h = len(samples) // 2
+            self._count_split(samples[:h], enc[:h], first)
+            self._count_split(samples[h:], enc[h:], first + h)
+
+    def _count(self, samples: list[str], enc: list[bytes], first: int) -> None:
         flat, offs = _lib.pack(enc)
         if self.split is None:
             keep = np.flatnonzero(offs[1:] > offs[:-1])
@@ -127,11 +151,11 @@ class VocabularyGenerator:
             pb, pe, ps = np.array(pb_l, np.uint64), np.array(pe_l, np.uint64), np.array(ps_l, np.uint32)
         extra = self.added_tokens + self.suggested_tokens
         extra_set = set(extra)
-        self.passes += 1
         if pb.size:
             # the keep rule sees the global sample index (the device packs it into 27 bits)
             pos, ln, df, _, _, cut = _lib.substring_df_top(flat, pb, pe, (ps.astype(np.uint64) + first).astype(np.uint32),
                                                            self.max_token_length, self.top_k, self.insert_probability, self.seed, self.device)
+            self.passes += 1  # (counted once the device has answered: a refused batch is retried in halves)
             self._bound_total += cut
             raw = flat.tobytes()
             for p_, l_, d_ in zip(pos.tolist(), ln.tolist(), df.tolist()):
@@ -194,8 +218,11 @@ class VocabularyGenerator:
             # pass that cut anything (its count is complete) and no substring outside the selection can reach the
             # frequency of the last one chosen: a cut-off substring occurs in at most `cutoff` samples of its pass.
             floor = last_freq if (last_freq is not None and len(vocab) >= size) else 0
-            if highest < self._bound_total:
-                raise _lib.TokenGeeXError("VocabularyGenerator: top_k too small: a substring that was cut off could be the most frequent one")
+            top = frequent[0][0] if frequent else None
+            if highest < self._bound_total or (top is not None and top not in extra and self._bound_seen.get(top, 0) != self._bound_total):
+                # (the most frequent substring's count is the score of every single-byte token: it must be complete too)
+                raise _lib.TokenGeeXError("VocabularyGenerator: top_k too small: the most frequent substring's count is incomplete, or a substring "
+                                          "that was cut off could be the most frequent one")
             for tok in chosen:
                 if self._bound_seen.get(tok, 0) != self._bound_total:
                     raise _lib.TokenGeeXError(f"VocabularyGenerator: top_k too small for an exact vocabulary: {tok!r} was cut off in some pass "
@@ -207,7 +234,8 @@ class VocabularyGenerator:
             for tok, freq in freqs.items():
                 if tok in chosen_set or tok in extra or len(tok.encode("utf-8", "surrogatepass")) <= 1:
                     continue
-                if freq + self._bound_total - self._bound_seen.get(tok, 0) >= floor and freq < floor:
+                missing = self._bound_total - self._bound_seen.get(tok, 0)  # what the passes that cut it off may have held
+                if missing > 0 and freq + missing >= floor:  # (also a substring AT the floor: its true count may exceed it)
                     raise _lib.TokenGeeXError(f"VocabularyGenerator: top_k too small for an exact vocabulary: {tok!r} may belong to it")
         vocab.sort(key=lambda t: (-t[1], t[0]))
         logsum = math.log(sum(t[1] for t in vocab))  # logprobs, src/generate.rs:245-251
