@@ -315,6 +315,38 @@ def test_long_token_vocabularies(monkeypatch, max_len, path):
         assert_same_encoding(nat3, ora3, f2, o2)
 
 
+@pytest.mark.parametrize("max_len", [16, 24])
+def test_token_end_mask_pipeline(monkeypatch, max_len):
+    """TGX_TRACE=mask (trace2.hip): the back-trace only marks token ends in a per-sample bit mask, a popcount scan
+    numbers the tokens, emit_kernel looks the ids up and writes them in place — no `tmp`, no compaction.  Kept as the
+    measured alternative (1.3 ms per GiB slower than trace + compact); ids, offsets and errors as the
+    default's: bit-exact against the oracle, with empty samples, dropout, samples of 1 .. 200 bytes (a word of the mask
+    and less) and an unreachable end."""
+    monkeypatch.setenv("TGX_TRACE", "mask")
+    rng = np.random.default_rng(77 + max_len)
+    flat, offs = synth.make_corpus(512 << 10, "mixed", seed_offset=31 + max_len, max_len=20000)
+    if max_len == 16:
+        toks, scores = synth.build_vocab(flat[: 256 << 10], 3000, 16)
+    else:
+        toks, scores = synth.random_vocab(rng, bytes(flat[: 96 << 10]), n_multi=4000, max_len=max_len, tie_fraction=0.5)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    assert_same_encoding(nat, ora, flat, offs)
+    kt = nat.last_kernel_times()
+    assert "mark_kernel" in kt and "emit_kernel" in kt and "compact_kernel" not in kt
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.3, seed=9)
+    texts = [b"", b"a", b"", b"ab" * 16, b"ab" * 32, b"ab" * 32 + b"a", b"q" * 63, b"q" * 64, b"q" * 65, b"", b"hello world " * 40, b""]
+    texts += [bytes(flat[i * 211: i * 211 + n]) for i, n in enumerate(range(1, 200))]
+    f2, o2 = tgx.pack(texts)
+    assert_same_encoding(nat, ora, f2, o2)
+    nat2, _ = _pair([b"a", b"b"], [-1.0, -1.0])  # test_no_path_reports_lowest_sample's case
+    f3, o3 = tgx.pack([b"ab", b"abc", b"a", b"!!", b""])
+    with pytest.raises(tgx.TokenGeeXError) as e:
+        nat2.encode_batch_flat(f3, o3)
+    assert str(e.value) == "no path to position 3/3"
+    assert (e.value.status, e.value.sample, e.value.pos, e.value.length) == (4, 1, 3, 3)
+    assert _enc(nat2, [b"abba", b"", b"b"]) == [[0, 1, 1, 0], [], [1]]
+
+
 def test_long_token_overflow_redoes_only_the_samples_concerned():
     """Every position of "aaaa..." matches sixteen tokens of 17..32 bytes: far more than a wave's overflow list
     holds, so the samples of such a wave are redone by encode2_kernel (and only those: the batch also has

@@ -31,6 +31,13 @@ struct EncodeParams {
     uint64_t seed;
     uint32_t flags;                 // timing experiments only (TGX_FLAGS env): see kernels.hip
     unsigned long long* stamps;     // diagnostic build only (TGX_STAMPS=1): 8 u64 per wave
+    // round 4 (trace2.hip): ids in their final place
+    unsigned long long* endmask;    // u64[mask_words + 1]: sample s owns words mword[s] .. mword[s + 1); bit j of its word k = "a token ends
+                                    // with the sample's byte 64 k + j" (every word is written by mark_kernel; the last is padding, 0)
+    const uint64_t* mword;          // u64[S + 1]: exclusive scan of ceil(n / 64) over the samples
+    uint64_t mask_words;            // mword[S]
+    const uint64_t* prefix;         // u64[mask_words + 1]: set bits before each word (launch_mask_scan)
+    uint32_t* ids_out;              // u32[T] the result's ids (emit_kernel)
 };
 
 // encode5_kernel / encode6_kernel (encode5.hip): 8-byte label-checked records, score values by rank
@@ -257,6 +264,12 @@ hipError_t encode4_waves_per_simd(bool dropout, int ppl, bool root, int* out);
 hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t blocks, bool root, hipStream_t stream);
 uint32_t encode4_lds_bytes(int waves, int ppl, bool root);
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream);
+// trace2.hip: mark_kernel (the hop chain alone: one bit per text byte), popcount scan, sample offsets, emit_kernel
+hipError_t launch_mark(const EncodeParams& p, uint32_t blocks, uint32_t lm, bool permuted, hipStream_t stream);
+hipError_t mask_scan_temp_bytes(uint64_t n_words, size_t* bytes);
+hipError_t launch_mask_scan(const unsigned long long* mask, uint64_t* prefix, uint64_t n_words, void* temp, size_t temp_bytes, hipStream_t stream);
+hipError_t launch_sample_offs(const uint64_t* mword, uint64_t n_samples, const uint64_t* prefix, uint64_t* out_offs, hipStream_t stream);
+hipError_t launch_emit(const EncodeParams& p, uint32_t lm, uint32_t num_cus, hipStream_t stream);
 uint32_t encode5_lds_layout(uint32_t n_hot, bool long_tokens, int waves, int ppl, uint32_t* list_off, uint32_t* root_off, uint32_t* idx_off);
 uint32_t encode5_max_hot(bool long_tokens, int waves, int ppl, uint32_t budget);
 hipError_t encode5_waves_per_simd(bool dropout, bool cold, int ppl, bool long_tokens, int* out);

@@ -200,6 +200,7 @@ struct tgx_model {
     uint64_t last_estep_pieces = 0;    // pieces the last E-step cut its snippets into (0: uncut)
     uint32_t last_corun_cus = 0;       // CUs the long-sample kernel had to itself beside encode5_kernel in the last pass (0: one after the other)
     uint64_t last_redo_samples = 0;    // samples the last encode4l pass left to encode2_kernel
+    bool mask_path = false;            // the last encode pass wrote the token-end mask (TGX_TRACE=mask: mark / scan / emit, trace2.hip)
     int last_encode_waves_per_cu = 0;  // resident waves per CU of the last rows4 encode launch (self-check)
     bool estep_linear_ok = false;   // tables for the linear-domain E-step kernels exist
     tgx::TokHashTable tokhash;      // token bytes -> id (rows4 trace); ok == false: not usable
@@ -247,6 +248,13 @@ struct tgx_corpus {
     uint32_t* d_status = nullptr;
     void* d_scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
+    // round 4 (trace2.hip): one bit per text byte ("a token ends here") and its popcount prefix, allocated on first pass
+    unsigned long long* d_endmask = nullptr;
+    uint64_t* d_prefix = nullptr;
+    uint64_t* d_mword = nullptr;       // u64[S + 1]: the samples' first mask words
+    void* d_mscan_tmp = nullptr;
+    size_t mscan_tmp_bytes = 0;
+    uint64_t mask_words = 0;
     // E-step work list of the corpus (every sample cut at multiples of snippet_len, longest snippet first) and its
     // device copies: built on the first pass with a given snippet length, reused by the following ones (prune
     // runs two E-steps per iteration over the same corpus; building and sorting the list took 5 of 65 ms at 1 GiB)
@@ -334,14 +342,30 @@ void time_end(tgx_model* m) {
     m->n_timed++;
 }
 
-tgx_status ensure_scratch(tgx_corpus* c) {
-    if (c->d_bp) return TGX_OK;
+// mask: the ids go through the token-end mask (TGX_TRACE=mask: mark / scan / emit, trace2.hip — the measured
+// alternative, 1.3 ms per GiB slower); else right-aligned in `tmp` and compacted (the default)
+tgx_status ensure_scratch(tgx_corpus* c, bool mask) {
+    const bool rows = mask;
     HIP_TRY(hipSetDevice(c->device));
-    // u32[N] for the one-sample-per-wave kernel; the rows4 kernels use it as bytes, N + 128 per sample
-    HIP_TRY(pool_alloc(c->device, std::max((size_t)c->n_bytes * 4 + 256, (size_t)c->n_bytes + 128 * (size_t)c->n_samples + 512), (void**)&c->d_bp));
-    HIP_TRY(pool_alloc(c->device, (size_t)c->n_bytes * 4 + 256, (void**)&c->d_tmp));
-    HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_counts));
-    HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_status));
+    if (!c->d_bp) {
+        // u32[N] for the one-sample-per-wave kernel; the rows4 kernels use it as bytes, N + 128 per sample
+        HIP_TRY(pool_alloc(c->device, std::max((size_t)c->n_bytes * 4 + 256, (size_t)c->n_bytes + 128 * (size_t)c->n_samples + 512), (void**)&c->d_bp));
+        HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_counts));
+        HIP_TRY(pool_alloc(c->device, (size_t)c->n_samples * 4 + 256, (void**)&c->d_status));
+    }
+    if (!rows && !c->d_tmp) HIP_TRY(pool_alloc(c->device, (size_t)c->n_bytes * 4 + 256, (void**)&c->d_tmp));
+    if (rows && !c->d_endmask) {
+        std::vector<uint64_t> mword(c->n_samples + 1, 0);  // sample s owns ceil(n / 64) words of the mask
+        for (uint64_t i = 0; i < c->n_samples; i++) mword[i + 1] = mword[i] + (c->h_offs[i + 1] - c->h_offs[i] + 63) / 64;
+        c->mask_words = mword[c->n_samples];
+        HIP_TRY(pool_alloc(c->device, (size_t)(c->n_samples + 1) * 8 + 256, (void**)&c->d_mword));
+        HIP_TRY(hipMemcpy(c->d_mword, mword.data(), (size_t)(c->n_samples + 1) * 8, hipMemcpyHostToDevice));
+        HIP_TRY(pool_alloc(c->device, (size_t)(c->mask_words + 1) * 8 + 256, (void**)&c->d_endmask));
+        HIP_TRY(hipMemset(c->d_endmask + c->mask_words, 0, 8));  // the word of padding (the scan's last element)
+        HIP_TRY(pool_alloc(c->device, (size_t)(c->mask_words + 1) * 8 + 256, (void**)&c->d_prefix));
+        HIP_TRY(tgx::mask_scan_temp_bytes(c->mask_words, &c->mscan_tmp_bytes));
+        if (c->mscan_tmp_bytes) HIP_TRY(pool_alloc(c->device, c->mscan_tmp_bytes, &c->d_mscan_tmp));
+    }
     return TGX_OK;
 }
 
@@ -355,7 +379,12 @@ uint32_t grid_blocks(const tgx_model* m, uint64_t n_samples) {
 // Runs the wave-per-sample kernel over the corpus; on return (stream synced)
 // h_ctrl[0] = min failing sample (~0 if none).
 tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64_t seed) {
-    tgx_status st = ensure_scratch(c);
+    {
+        const char* force0 = knob("TGX_PATH");
+        const char* tr = knob("TGX_TRACE");
+        m->mask_path = tr && strcmp(tr, "mask") == 0 && m->lm <= 32 && m->scores_finite && m->d_tokhash && !(force0 && strcmp(force0, "fused") == 0);
+    }
+    tgx_status st = ensure_scratch(c, m->mask_path);
     if (st != TGX_OK) return st;
     HIP_TRY(hipMemsetAsync(m->d_ctrl, 0x00, 8, m->stream));
     HIP_TRY(hipMemsetAsync(m->d_ctrl + 1, 0xFF, 8, m->stream));
@@ -381,6 +410,10 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     p.queue = m->d_ctrl;
     p.dropout = dropout;
     p.seed = seed;
+    p.endmask = c->d_endmask;
+    p.mword = c->d_mword;
+    p.mask_words = c->mask_words;
+    p.prefix = c->d_prefix;
     {
         // timing experiments (tools/ablate.py) — results are WRONG when set; honoured only with TGX_DEBUG=1
         const char* f = debug_on() ? getenv("TGX_FLAGS") : nullptr;
@@ -756,8 +789,9 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         p.n_samples = c->n_samples;
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
-        time_begin(m, long_tokens ? "trace32_kernel" : "trace_kernel");
-        if (long_tokens) HIP_TRY(tgx::launch_trace32(p, blocks_t, true, m->stream));
+        time_begin(m, m->mask_path ? "mark_kernel" : long_tokens ? "trace32_kernel" : "trace_kernel");
+        if (m->mask_path) HIP_TRY(tgx::launch_mark(p, blocks_t, long_tokens ? 32u : 16u, true, m->stream));
+        else if (long_tokens) HIP_TRY(tgx::launch_trace32(p, blocks_t, true, m->stream));
         else HIP_TRY(tgx::launch_trace(p, blocks_t, m->stream));
         time_end(m);
     } else if (use4) {
@@ -838,21 +872,6 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         }
         time_begin(m, "encode4_kernel");
         HIP_TRY(tgx::launch_encode4(p, ppl, waves, blocks4, root, m->stream));
-        if (p.flags & 64u) {
-            // experiment (TGX_DEBUG=1 TGX_FLAGS=64): trace_kernel over the PREVIOUS pass's back-pointers (same
-            // corpus: same bytes) on a second stream while encode4_kernel runs; the timed pair covers both
-            static hipStream_t s2 = nullptr;
-            static hipEvent_t ev0 = nullptr, ev1 = nullptr;
-            if (!s2) {
-                HIP_TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
-            }
-            const uint32_t bt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
-            HIP_TRY(tgx::launch_trace(p, bt, s2));
-            HIP_TRY(hipEventRecord(ev1, s2));
-            HIP_TRY(hipStreamWaitEvent(m->stream, ev1, 0));
-        }
         time_end(m);
         if (d_stamps) {  // diagnostic: mean cycles per iteration and phase over all waves
             std::vector<unsigned long long> h(n_stamp_waves * 8);
@@ -872,32 +891,10 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
         p.n_samples = c->n_samples;
         const uint32_t blocks_t =
             (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((c->n_samples + 3) / 4, (uint64_t)m->num_cus * 8));
-        unsigned long long* d_tstamps = nullptr;
-        const size_t n_twaves = (size_t)blocks_t * 4;
-        if (const char* e = debug_on() ? getenv("TGX_STAMPS") : nullptr) {
-            if (*e == '2') {
-                HIP_TRY(hipMalloc((void**)&d_tstamps, n_twaves * 64));
-                HIP_TRY(hipMemsetAsync(d_tstamps, 0, n_twaves * 64, m->stream));
-                p.stamps = d_tstamps;
-            }
-        }
-        time_begin(m, "trace_kernel");
-        HIP_TRY(tgx::launch_trace(p, blocks_t, m->stream));
+        time_begin(m, m->mask_path ? "mark_kernel" : "trace_kernel");
+        if (m->mask_path) HIP_TRY(tgx::launch_mark(p, blocks_t, 16u, true, m->stream));
+        else HIP_TRY(tgx::launch_trace(p, blocks_t, m->stream));
         time_end(m);
-        if (d_tstamps) {
-            std::vector<unsigned long long> h(n_twaves * 8);
-            HIP_TRY(hipStreamSynchronize(m->stream));
-            HIP_TRY(hipMemcpy(h.data(), d_tstamps, n_twaves * 64, hipMemcpyDeviceToHost));
-            double sum[5] = {0, 0, 0, 0, 0}, iters = 0;
-            for (size_t w = 0; w < n_twaves; w++) {
-                for (int i = 0; i < 5; i++) sum[i] += (double)h[w * 8 + i];
-                iters += (double)h[w * 8 + 5];
-            }
-            fprintf(stderr, "[tgx] trace stamps (ticks per window, %zu waves, %.0f windows): setup %.0f  loads %.0f  hops %.0f  tokens %.0f\n",
-                    n_twaves, iters, sum[0] / iters, sum[1] / iters, sum[2] / iters, sum[3] / iters);
-            (void)hipFree(d_tstamps);
-            p.stamps = nullptr;
-        }
     } else if (use2) {
         // Tokens of 17..32 bytes: the 16-lane rows with an overflow list for the long matches (encode4l.hip);
         // samples whose wave ran out of overflow entries are redone two per wave on 32-lane rows (encode2.hip),
@@ -932,8 +929,9 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
             HIP_TRY(tgx::launch_encode2(p, (uint32_t)m->num_cus, false, m->stream));
             time_end(m);
         }
-        time_begin(m, "trace32_kernel");
-        HIP_TRY(tgx::launch_trace32(p, blocks_t, !rows2, m->stream));
+        time_begin(m, m->mask_path ? "mark_kernel" : "trace32_kernel");
+        if (m->mask_path) HIP_TRY(tgx::launch_mark(p, blocks_t, 32u, !rows2, m->stream));
+        else HIP_TRY(tgx::launch_trace32(p, blocks_t, !rows2, m->stream));
         time_end(m);
     } else {
         time_begin(m, "encode_kernel");
@@ -947,7 +945,7 @@ tgx_status check_no_path(tgx_model* m, const tgx_corpus* c) {
     unsigned long long bad = m->h_ctrl[0];
     if (bad == ~0ULL) return TGX_OK;
     if (bad & (1ULL << 62))
-        return fail(TGX_ERR_DEVICE, "internal error: corrupt back-pointer in sample %llu",
+        return fail(TGX_ERR_DEVICE, "internal error: corrupt back-pointer (sample or text byte %llu)",
                     (unsigned long long)(bad & ~(1ULL << 62)));
     uint64_t n = c->h_offs[bad + 1] - c->h_offs[bad];
     g_err_sample = bad;
@@ -1501,10 +1499,14 @@ void tgx_corpus_free(tgx_corpus* c) {
     pool_free(c->device, c->d_offs, (size_t)(c->n_samples + 1) * 8);
     pool_free(c->device, c->d_order, (size_t)c->n_samples * 4 + 4);
     pool_free(c->device, c->d_bp, std::max((size_t)c->n_bytes * 4 + 256, (size_t)c->n_bytes + 128 * (size_t)c->n_samples + 512));
-    pool_free(c->device, c->d_tmp, (size_t)c->n_bytes * 4 + 256);
+    if (c->d_tmp) pool_free(c->device, c->d_tmp, (size_t)c->n_bytes * 4 + 256);
     pool_free(c->device, c->d_counts, (size_t)c->n_samples * 4 + 256);
     pool_free(c->device, c->d_status, (size_t)c->n_samples * 4 + 256);
     pool_free(c->device, c->d_scan_tmp, c->scan_tmp_bytes);
+    pool_free(c->device, c->d_endmask, (size_t)(c->mask_words + 1) * 8 + 256);
+    pool_free(c->device, c->d_prefix, (size_t)(c->mask_words + 1) * 8 + 256);
+    pool_free(c->device, c->d_mscan_tmp, c->mscan_tmp_bytes);
+    pool_free(c->device, c->d_mword, (size_t)(c->n_samples + 1) * 8 + 256);
     pool_free(c->device, c->es.d_soffs, c->es.obytes);
     pool_free(c->device, c->es.d_sbase, c->es.obytes);
     pool_free(c->device, c->es.d_order, c->es.ordbytes);
@@ -1542,6 +1544,46 @@ static tgx_status encode_corpus_locked(tgx_model* m, tgx_corpus* c, double dropo
 
     tgx_status st = run_encode_kernel(m, c, dropout, seed);
     if (st != TGX_OK) return cleanup(st);
+    if (m->mask_path) {
+        // TGX_TRACE=mask: ids in their final place (trace2.hip): the mask's popcount prefix gives every token its index, the batch its
+        // token count and every sample its offset; emit_kernel turns set bits into ids, fully parallel
+        time_begin(m, "mask_scan");
+        if (tgx::launch_mask_scan(c->d_endmask, c->d_prefix, c->mask_words, c->d_mscan_tmp, c->mscan_tmp_bytes, m->stream) != hipSuccess ||
+            tgx::launch_sample_offs(c->d_mword, S, c->d_prefix, r->d_offs, m->stream) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "mask scan launch failed"));
+        time_end(m);
+        if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipMemcpyAsync(&m->h_ctrl[1], c->d_prefix + c->mask_words, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "encode pass failed: %s", hipGetErrorString(hipGetLastError())));
+        st = check_no_path(m, c);
+        if (st != TGX_OK) return cleanup(st);
+        r->n_tokens = m->h_ctrl[1];
+        if (pool_alloc(m->device, (size_t)r->n_tokens * 4 + 256, (void**)&r->d_ids) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "out of device memory (result ids)"));
+        tgx::EncodeParams pe{};
+        pe.text = c->d_text;
+        pe.tokhash = m->d_tokhash;
+        pe.tokhash_mask = m->tokhash.mask;
+        pe.tokhash_seed = m->tokhash.seed;
+        pe.err_sample = m->d_ctrl + 1;
+        pe.offs = c->d_offs;
+        pe.n_samples = S;
+        pe.endmask = c->d_endmask;
+        pe.mword = c->d_mword;
+        pe.mask_words = c->mask_words;
+        pe.prefix = c->d_prefix;
+        pe.ids_out = r->d_ids;
+        time_begin(m, "emit_kernel");
+        if (tgx::launch_emit(pe, m->lm <= 16 ? 16u : 32u, (uint32_t)m->num_cus, m->stream) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "emit launch failed"));
+        time_end(m);
+        if (hipMemcpyAsync(&m->h_ctrl[0], m->d_ctrl + 1, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+            hipStreamSynchronize(m->stream) != hipSuccess)
+            return cleanup(fail(TGX_ERR_DEVICE, "emit failed: %s", hipGetErrorString(hipGetLastError())));
+        st = check_no_path(m, c);  // (a lookup that missed: "corrupt back-pointer", never a fault)
+        if (st != TGX_OK) return cleanup(st);
+    } else {
     if (!c->d_scan_tmp) {  // scratch of the device-wide scan (large sample counts only), kept on the corpus
         if (tgx::scan_temp_bytes(S, &c->scan_tmp_bytes) != hipSuccess)
             return cleanup(fail(TGX_ERR_DEVICE, "scan temp-size query failed"));
@@ -1581,6 +1623,7 @@ static tgx_status encode_corpus_locked(tgx_model* m, tgx_corpus* c, double dropo
     time_end(m);
     if (hipStreamSynchronize(m->stream) != hipSuccess)
         return cleanup(fail(TGX_ERR_DEVICE, "compact failed: %s", hipGetErrorString(hipGetLastError())));
+    }
     // N + 4T + 16(S+1)
     m->last_alg_bytes = c->n_bytes + 4 * r->n_tokens + 16 * (S + 1);
     *out = r;
