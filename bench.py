@@ -261,14 +261,17 @@ def main() -> None:
         # cannot be read inside this process): the committed figure of the profiled build, with its source
         # named, and only for the workload it was taken on; null otherwise
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
-        if os.path.exists(tpath) and (args.size_mb, args.vocab, args.kind, args.max_token_length, args.max_sample_len, args.distinct_scores, args.vocab_slice_mb) == (1024, 32000, "mixed", 16, 65536, False, 64):
+        tpath = _traffic_file()
+        if tpath and (args.size_mb, args.vocab, args.kind, args.max_token_length, args.max_sample_len, args.distinct_scores, args.vocab_slice_mb) == (1024, 32000, "mixed", 16, 65536, False, 64):
             with open(tpath) as f:
                 tj = json.load(f)
-            enc = lambda names: {k.split("<")[0] for k in names if k.startswith("encode")}
-            if enc(tj.get("kernels", {})) == enc(per_step):  # same encode kernels as this build
+            enc = lambda names: {k.split("<")[0] for k in names if k.startswith(("encode", "estep"))}
+            if enc(tj.get("kernels", {})) == enc(per_step):  # same encode kernels as the profiled build
                 traffic = tj.get("hbm_bytes_per_pass_corrected")
-                traffic_source = f"profiles/r03/pmc_traffic.json ({tj.get('commit', '?')})"
+                traffic_source = f"{os.path.relpath(tpath, ROOT)} ({tj.get('commit', '?')})"
+            if estep and enc(tj.get("estep_kernels", {})) == {k.split("<")[0] for k in estep["kernel_ms_per_step"] if k.startswith("estep")} and tj.get("estep_hbm_bytes_per_pass_corrected"):
+                estep["roofline"]["traffic"] = tj["estep_hbm_bytes_per_pass_corrected"]
+                estep["roofline"]["traffic_source"] = traffic_source
         out = {
             "metric": "MB/s raw bytes encoded (and tokens/s) at 32K/64K vocab, 1/2/4/8 GPUs",
             "value": round(mb_s, 2),
@@ -362,6 +365,15 @@ def cpu_baseline(toks, scores, flat, offs, model, target_seconds: float) -> dict
             "tokens_per_s": round(float(ids.size) / dt, 1),
             "value_1thread": round(float(offs[k1]) / dt1 / 1e6, 2),
             "sample_1thread": f"first {k1} samples ({int(offs[k1])} bytes), 1 thread, {dt1:.1f} s"}
+
+
+def _traffic_file():
+    """The newest committed PMC traffic record (tools/pmc_traffic.sh): profiles/rNN/pmc_traffic.json."""
+    for rnd in ("r04", "r03"):
+        p = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        if os.path.exists(p):
+            return p
+    return None
 
 
 def cpu_baseline_estep(toks, scores, flat, offs, model, target_seconds: float) -> dict:

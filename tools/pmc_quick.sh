@@ -10,9 +10,10 @@ i=0
 for P in "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" \
          "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-         "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_VALU"; do
+         "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_VALU" \
+         "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCC_EA0_ATOMIC_sum"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e "$@" > $OUT/g$i.log 2>&1 || { echo "group $i failed: stopping"; break; }
+  timeout -k 10 200 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/g$i -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-distinct "$@" > $OUT/g$i.log 2>&1 || { echo "group $i failed: stopping"; break; }
 done
 python3 - $OUT <<'PY'
 import csv, glob, collections, sys
