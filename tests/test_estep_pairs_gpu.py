@@ -511,3 +511,36 @@ def test_estep7_with_more_than_65535_tokens():
     _check_estep(nat, ora, flat, offs)
     assert "estep7_kernel" in nat.last_kernel_times()
     _check_estep(nat, ora, flat, offs, dropout=0.1, seed=2)
+
+
+def test_estep7_after_an_m_step_ranks_by_match_counts(monkeypatch):
+    """prune's second sub-iteration (src/prune.rs:36-56): the E-step of a DERIVED model with the scores an M-step leaves
+    — kept single-byte tokens with tiny scores that still match at every occurrence of their byte.  The ranks that stay in
+    LDS come from match counts over a sample of the corpus (tgx_api.cpp ensure_estep_trie8t); the result must not depend
+    on that choice: the same expected counts with the model's own order (TGX_E7_RANK=model), with a small table
+    (TGX_E7_HOT) and against the oracle."""
+    from tokengeex_amd import _lib
+    flat, offs = synth.make_corpus(3 << 20, "mixed", seed_offset=91)
+    toks, scores = synth.build_vocab(flat[: 1 << 20], 20000, 16)
+    nat, _ = _pair(toks, scores)
+    corpus = tgx.NativeCorpus(flat, offs)
+    exp, _ = nat.estep(corpus)
+    keep = np.array([1 if len(t) == 1 else 0 for t in toks], np.uint8)
+    idx, sc2 = _lib.prune_m_step(exp, keep)
+    idx, sc2 = np.asarray(idx, np.uint32), np.asarray(sc2, np.float64)
+    assert 1000 < idx.size < len(toks)
+    toks2 = [toks[i] for i in idx]
+    ora2 = orc.OracleModel(toks2, sc2)
+    derived = nat.derive(idx, sc2, for_estep=True)
+    got, gz = _check_estep(derived, ora2, flat, offs, dropout=0.05, seed=4)
+    assert "estep7_kernel" in derived.last_kernel_times()
+    monkeypatch.setenv("TGX_E7_RANK", "model")
+    plain = nat.derive(idx, sc2, for_estep=True)
+    got2, gz2 = plain.estep(corpus, 81920, 0.05, 4)
+    np.testing.assert_allclose(got2, got, rtol=1e-9, atol=ATOL)
+    assert abs(gz2 - gz) <= 1e-12 * abs(gz)
+    monkeypatch.delenv("TGX_E7_RANK")
+    monkeypatch.setenv("TGX_E7_HOT", "300")
+    small = tgx.NativeModel(toks2, sc2, for_estep=True)
+    got3, _ = small.estep(corpus, 81920, 0.05, 4)
+    np.testing.assert_allclose(got3, got, rtol=1e-9, atol=ATOL)

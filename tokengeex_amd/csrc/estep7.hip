@@ -853,6 +853,57 @@ uint32_t estep7_lds_layout(uint32_t n_hot, bool wide, int waves, int ppl, uint32
     if (idx_off) *idx_off = io;
     return io + (uint32_t)waves * (uint32_t)ppl * gb;
 }
+// ---- match counts over a sample of the text (which ranks deserve the LDS) -------------------------------------------
+// One thread per position: the walk of estep7_kernel, one count per token met.  The first kCountLds ranks (the provisional
+// order puts the likely winners there) are counted in the block's LDS and flushed once; the others — and there may be a
+// frequent one among them, which is the point of counting — go to memory directly: the sample is small.
+constexpr uint32_t kCountLds = 16384;
+__global__ __launch_bounds__(256) void match_count_kernel(const uint8_t* __restrict__ text, uint64_t n_bytes, uint32_t chunk, uint64_t stride,
+                                                          const uint2* __restrict__ trie, uint32_t n_slots, uint32_t root_base, uint32_t n_tok,
+                                                          unsigned int* __restrict__ counts) {
+    __shared__ unsigned int hist[kCountLds];
+    for (uint32_t i = threadIdx.x; i < kCountLds; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    const uint64_t n_chunks = (n_bytes + stride - 1) / stride;
+    const uint64_t total = n_chunks * chunk;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = (i / chunk) * stride + (i % chunk);
+        if (p >= n_bytes) continue;
+        const uint32_t reach = (uint32_t)(n_bytes - p < 16u ? n_bytes - p : 16u);
+        uint32_t t = root_base ^ text[p];
+        for (uint32_t k = 0; k < reach; ++k) {
+            if (t >= n_slots) break;
+            const uint2 rec = trie[t];
+            if ((rec.x >> 24) != text[p + k]) break;
+            if (rec.y) {
+                if (rec.y < kCountLds) atomicAdd(&hist[rec.y], 1u);
+                else if (rec.y <= n_tok) atomicAdd(&counts[rec.y], 1u);
+            }
+            if (k + 1u < reach) t = (rec.x ^ (uint32_t)text[p + k + 1u]) & 0xFFFFFFu;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kCountLds; i += blockDim.x)
+        if (hist[i] && i <= n_tok) atomicAdd(&counts[i], hist[i]);
+}
+__global__ __launch_bounds__(256) void rank_remap_kernel(uint2* __restrict__ trie, uint32_t n_slots, const uint32_t* __restrict__ perm) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slots) return;
+    const uint32_t r = trie[t].y;
+    if (r) trie[t].y = perm[r];
+}
+hipError_t launch_match_count(const uint8_t* text, uint64_t n_bytes, uint32_t chunk, uint64_t stride, const void* trie8t, uint32_t n_slots,
+                              uint32_t root_base, uint32_t n_tok, unsigned int* counts, uint32_t num_cus, hipStream_t stream) {
+    if (!n_bytes || !chunk || stride < chunk) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(match_count_kernel, dim3(num_cus * 4u), dim3(256), 0, stream, text, n_bytes, chunk, stride,
+                       reinterpret_cast<const uint2*>(trie8t), n_slots, root_base, n_tok, counts);
+    return hipGetLastError();
+}
+hipError_t launch_rank_remap(void* trie8t, uint32_t n_slots, const uint32_t* perm, hipStream_t stream) {
+    hipLaunchKernelGGL(rank_remap_kernel, dim3((n_slots + 255u) / 256u), dim3(256), 0, stream, reinterpret_cast<uint2*>(trie8t), n_slots, perm);
+    return hipGetLastError();
+}
+
 uint32_t estep7_max_hot(bool wide, int waves, int ppl, uint32_t budget) {
     const uint32_t fixed = estep7_lds_layout(0u, wide, waves, ppl, nullptr, nullptr, nullptr) + (wide ? 4096u : 2048u);  // alignment slack
     return budget > fixed + 64u ? (budget - fixed) / 16u : 0u;

@@ -238,6 +238,13 @@ uint32_t estep7_lds_layout(uint32_t n_hot, bool wide, int waves, int ppl, uint32
 uint32_t estep7_max_hot(bool wide, int waves, int ppl, uint32_t budget);
 hipError_t estep7_waves_per_simd(bool dropout, bool cold, bool wide, int ppl, int* out);
 hipError_t launch_estep7(Estep7Params p, bool wide, int ppl, int waves, uint32_t blocks, hipStream_t stream);
+// How often every token MATCHES in a sample of the text (chunks of `chunk` bytes every `stride` bytes): counts[rank] += 1
+// per position of the sample and token that is a prefix of the text there.  The E-step adds to a token's expected count
+// once per match, whatever its score: the ranks that stay in LDS are chosen by these counts (tgx_api.cpp).
+hipError_t launch_match_count(const uint8_t* text, uint64_t n_bytes, uint32_t chunk, uint64_t stride, const void* trie8t, uint32_t n_slots,
+                              uint32_t root_base, uint32_t n_tok, unsigned int* counts, uint32_t num_cus, hipStream_t stream);
+// rec[t].tok = perm[rec[t].tok] for every slot of the 8-byte E-step records
+hipError_t launch_rank_remap(void* trie8t, uint32_t n_slots, const uint32_t* perm, hipStream_t stream);
 hipError_t launch_snip_z_check(const double* zsnip, uint64_t n_snips, unsigned long long* err_snip, hipStream_t stream);
 hipError_t launch_piece_z_add(const double* zarr, const uint32_t* psnip, const uint32_t* order, uint64_t n_order, double* zsnip, hipStream_t stream);
 

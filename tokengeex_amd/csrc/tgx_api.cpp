@@ -997,6 +997,7 @@ static tgx_status ensure_encode_tables(tgx_model* m) {
     HIP_TRY(hipSetDevice(m->device));
     // the bytes -> id table and the 8-byte records are independent: the first is built on a second host thread
     // while this one builds the second (each ~50 ms at 500 000 tokens)
+    tgx::HostPhases hp("ensure_encode_tables");
     const bool want_hash = m->lm <= 32 && m->scores_finite;
     const bool want_trie8 = m->lm <= 32 && m->scores_finite && m->flat.table.size() <= tgx::kTrie8MaxSlots;
     std::thread hash_builder;
@@ -1005,6 +1006,7 @@ static tgx_status ensure_encode_tables(tgx_model* m) {
     tgx::Trie8 t8;
     if (want_trie8) tgx::build_trie8(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), &t8);
     if (hash_builder.joinable()) hash_builder.join();
+    hp.mark("trie8 | tok hash");
     // (a failure part-way leaves the tables that exist in place, pointers set: the next call finds them — nothing is
     // allocated twice — and tgx_model_destroy frees them)
     if (want_hash && m->tokhash.ok && !m->d_tokhash) {
@@ -1024,6 +1026,7 @@ static tgx_status ensure_encode_tables(tgx_model* m) {
         m->have_trie8 = true;
     }
     HIP_TRY(hipStreamSynchronize(m->stream));
+    hp.mark("uploads");
     m->encode_tables_ready = true;
     return TGX_OK;
 }
@@ -1047,6 +1050,7 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
     if (device < 0 || device >= ndev)
         return fail(TGX_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
 
+    tgx::HostPhases hp("tgx_model_create");
     tgx_model* m = new tgx_model();
     m->device = device;
     m->vocab_size = vocab_size;
@@ -1088,7 +1092,9 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
             });
         }
     }
+    hp.mark("scan of the vocabulary");
     tgx::build_flat_trie(bytes, vocab_size ? offs : zero_offs, scores, vocab_size, &m->flat);
+    hp.mark("build_flat_trie");
     if (hash_early.joinable()) {
         hash_early.join();
         m->tokhash_host_built = true;
@@ -1097,7 +1103,10 @@ tgx_status tgx_model_create_ex(const uint8_t* bytes, const uint64_t* offs, const
         rev_builder.join();
         m->rev_host_built = true;
     }
-    return finish_model_create(m, bytes, offs, scores, vocab_size, device, flags, out);
+    hp.mark("join hash / reverse builders");
+    const tgx_status fst = finish_model_create(m, bytes, offs, scores, vocab_size, device, flags, out);
+    hp.mark("finish (device tables)");
+    return fst;
 }
 
 // the part of model creation after the host tables exist: checks, device tables, uploads
@@ -1184,6 +1193,7 @@ tgx_status tgx_model_create_derived(const tgx_model* parent, const uint32_t* kee
     if (!out) return fail(TGX_ERR_INVALID, "tgx_model_create_derived: out is NULL");
     *out = nullptr;
     if (!parent || (n_keep && (!keep_ids || !scores))) return fail(TGX_ERR_INVALID, "tgx_model_create_derived: NULL argument");
+    tgx::HostPhases hp("tgx_model_create_derived");
     const uint32_t PV = parent->vocab_size;
     for (uint32_t i = 0; i < n_keep; i++)
         if (keep_ids[i] >= PV || (i && keep_ids[i] <= keep_ids[i - 1])) return fail(TGX_ERR_INVALID, "tgx_model_create_derived: keep_ids must ascend within the parent's vocabulary");
@@ -1212,6 +1222,7 @@ tgx_status tgx_model_create_derived(const tgx_model* parent, const uint32_t* kee
         const uint64_t b = parent->vocab_offs[keep_ids[i]], e = parent->vocab_offs[keep_ids[i] + 1];
         if (e > b) memcpy(bytes.data() + offs[i], parent->vocab_bytes.data() + b, (size_t)(e - b));
     }
+    hp.mark("checks + bytes");
     auto derive = [&](const tgx::FlatTrie& src, tgx::FlatTrie* dst) {
         *dst = src;
         dst->max_token_len = longest;
@@ -1251,7 +1262,10 @@ tgx_status tgx_model_create_derived(const tgx_model* parent, const uint32_t* kee
         m->rev_host_built = true;
     }
     parent_lock.unlock();
-    return finish_model_create(m, bytes.data(), offs.data(), scores, n_keep, parent->device, flags, out);
+    hp.mark("derive tables");
+    const tgx_status fst = finish_model_create(m, bytes.data(), offs.data(), scores, n_keep, parent->device, flags, out);
+    hp.mark("finish (device tables)");
+    return fst;
 }
 
 // tgx_prune_alternatives over the model's own double-array (the prune driver has a model of the same vocabulary
@@ -2490,20 +2504,87 @@ static tgx_status estep_pieces_build(tgx_model* m, tgx_corpus* c, const void* tr
 // The token-ranked records and weights of estep7_kernel (estep7.hip): vocabularies with finite scores within +-300
 // (w = exp(score) and its products must stay inside the f64 range, as for the other linear-domain kernels) and tokens of
 // at most 16 bytes.  ~40 ns of host time per token.
-static tgx_status ensure_estep_trie8t(tgx_model* m) {
+// The 8-byte records of estep7_kernel.  Built at the model's first E-step, where there is text: the ranks that the kernels
+// keep in LDS are the tokens that MATCH most often in a sample of the corpus (match_count_kernel) — every match is one add
+// to the token's expected count, whatever its score, and adds outside LDS are memory-side atomics that queue up per
+// address.  (Ranked by exp(score) / length, prune's second sub-iteration at 500 000 entries — M-step scores — left one
+// token with 1.9 M matches outside: 61 ms against the first sub-iteration's 13; ranked by the probability mass below
+// the token's node, 74 ms.)
+static tgx_status ensure_estep_trie8t(tgx_model* m, const tgx_corpus* c) {
     if (m->trie8t_tried) return TGX_OK;
     m->trie8t_tried = true;
     if (!(m->lm <= 16 && m->scores_finite && m->vocab_size && m->flat.table.size() <= tgx::kTrie8TMaxSlots)) return TGX_OK;
     for (uint32_t i = 0; i < m->vocab_size; i++)
         if (!(m->vocab_scores[i] >= -300.0 && m->vocab_scores[i] <= 300.0)) return TGX_OK;
+    tgx::HostPhases hp("ensure_estep_trie8t");
     tgx::Trie8T t8;
     tgx::build_trie8t(m->flat, m->vocab_offs.data(), m->vocab_scores.data(), &t8);
     if (!t8.ok || t8.n_tok == 0) return TGX_OK;
+    hp.mark("build_trie8t");
     HIP_TRY(hipSetDevice(m->device));
     const size_t ns = t8.rec.size(), nw = t8.w.size();
     if (!m->d_trie8t) HIP_TRY(hipMalloc(&m->d_trie8t, ns * sizeof(tgx::Trie8TRec)));
     if (!m->d_wtab) HIP_TRY(hipMalloc((void**)&m->d_wtab, nw * 8));
     HIP_TRY(hipMemcpy(m->d_trie8t, t8.rec.data(), ns * sizeof(tgx::Trie8TRec), hipMemcpyHostToDevice));
+    hp.mark("upload records");
+    const char* norank = knob("TGX_E7_RANK");  // "model": keep build_trie8t's order (measurements)
+    if (c && c->n_bytes && !(norank && strcmp(norank, "model") == 0)) {
+        // up to 64 chunks of 64 KiB spread over the corpus (4 MiB: ~13 M matches)
+        const uint32_t chunk = 65536u;
+        const uint64_t stride = std::max<uint64_t>(chunk, (c->n_bytes + 63) / 64);
+        unsigned int* d_cnt = nullptr;
+        uint32_t* d_perm = nullptr;
+        const size_t cb = nw * 4 + 256;
+        auto drop = [&]() {
+            pool_free(m->device, d_cnt, cb);
+            pool_free(m->device, d_perm, cb);
+        };
+        if (pool_alloc(m->device, cb, (void**)&d_cnt) != hipSuccess || pool_alloc(m->device, cb, (void**)&d_perm) != hipSuccess) {
+            drop();
+            return fail(TGX_ERR_DEVICE, "out of device memory (match counts)");
+        }
+        std::vector<unsigned int> cnt(nw, 0u);
+        if (hipMemsetAsync(d_cnt, 0, cb, m->stream) != hipSuccess ||
+            tgx::launch_match_count(c->d_text, c->n_bytes, chunk, stride, m->d_trie8t, (uint32_t)ns, t8.root_base, t8.n_tok, d_cnt, (uint32_t)m->num_cus, m->stream) != hipSuccess ||
+            hipMemcpyAsync(cnt.data(), d_cnt, nw * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) {
+            drop();
+            return fail(TGX_ERR_DEVICE, "match count pass failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        hp.mark("match counts");
+        // new order: the kTrie8TSortedRanks most matched tokens by descending count (ties: the old rank), the others as they were
+        const uint32_t n_tok = t8.n_tok;
+        std::vector<uint32_t> order(n_tok);
+        for (uint32_t r = 0; r < n_tok; r++) order[r] = r + 1u;
+        const auto hotter = [&](uint32_t a, uint32_t b) { return cnt[a] != cnt[b] ? cnt[a] > cnt[b] : a < b; };
+        const size_t head = std::min<size_t>(n_tok, tgx::kTrie8TSortedRanks);
+        if (head < n_tok) {
+            std::nth_element(order.begin(), order.begin() + (long)head, order.end(), hotter);
+            // the others in their old order, without a sort: mark the head, read the marks in order
+            std::vector<uint8_t> in_head(nw, 0);
+            for (size_t i = 0; i < head; i++) in_head[order[i]] = 1;
+            size_t k = head;
+            for (uint32_t r = 1; r <= n_tok; r++)
+                if (!in_head[r]) order[k++] = r;
+        }
+        std::sort(order.begin(), order.begin() + (long)head, hotter);
+        std::vector<uint32_t> perm(nw, 0u);
+        std::vector<double> w2(nw, 0.0);
+        std::vector<uint32_t> id2(nw, tgx::kNoToken);
+        for (uint32_t r = 0; r < n_tok; r++) {
+            perm[order[r]] = r + 1u;
+            w2[r + 1u] = t8.w[order[r]];
+            id2[r + 1u] = t8.id_of_rank[order[r]];
+        }
+        t8.w.swap(w2);
+        t8.id_of_rank.swap(id2);
+        if (hipMemcpyAsync(d_perm, perm.data(), nw * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
+            tgx::launch_rank_remap(m->d_trie8t, (uint32_t)ns, d_perm, m->stream) != hipSuccess || hipStreamSynchronize(m->stream) != hipSuccess) {
+            drop();
+            return fail(TGX_ERR_DEVICE, "rank remap failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        drop();
+        hp.mark("re-rank");
+    }
     HIP_TRY(hipMemcpy(m->d_wtab, t8.w.data(), nw * 8, hipMemcpyHostToDevice));
     m->id_of_rank = std::move(t8.id_of_rank);
     m->n_tok7 = t8.n_tok;
@@ -2518,15 +2599,18 @@ static tgx_status ensure_estep_trie8t(tgx_model* m) {
 static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len, double dropout, uint64_t seed, double* expected,
                               double* logz_sum, bool* fallback) {
     *fallback = false;
+    tgx::HostPhases hp("estep_fused");
     {
-        const tgx_status tst = ensure_estep_trie8t(m);
+        const tgx_status tst = ensure_estep_trie8t(m, c);
         if (tst != TGX_OK) return tst;
         if (!m->have_trie8t) {
             *fallback = true;
             return TGX_OK;
         }
+        hp.mark("trie8t");
         const tgx_status wst = ensure_estep_work(m, c, snippet_len);
         if (wst != TGX_OK) return wst;
+        hp.mark("work list");
     }
     tgx_corpus::EstepWork& es = c->es;
     const uint64_t S = c->n_samples, N = c->n_bytes, K = es.soffs.size() - 1;
@@ -2659,6 +2743,7 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         const char* f = debug_on() ? getenv("TGX_FLAGS") : nullptr;
         p.flags = f ? (uint32_t)atoi(f) : 0u;
     }
+    hp.mark("pieces + buffers");
     time_begin(m, "estep7_kernel");
     if (tgx::launch_estep7(p, wide, ppl, waves, blocks, m->stream) != hipSuccess) {
         pool_free(m->device, d_stamps, n_stamp_waves * 64);
@@ -2757,6 +2842,7 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             return cleanup(TGX_OK);
         }
     }
+    hp.mark("kernel + redo");
     if (tgx::launch_snip_z_check(d_zsnip, K, m->d_ctrl + 1, m->stream) != hipSuccess) return cleanup(fail(TGX_ERR_DEVICE, "z check launch failed"));
     std::vector<double> h((size_t)m->n_tok7 + 1);
     double hz = 0.0;
@@ -2773,7 +2859,9 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         return cleanup(fail(TGX_ERR_Z_NOT_NORMAL, "normalization constant is not a normal number (sample %llu, len=%llu)",
                             (unsigned long long)smp, (unsigned long long)g_err_len));  // src/prune.rs:90-96
     }
+    hp.mark("download");
     for (uint32_t r = 1; r <= m->n_tok7; r++) expected[m->id_of_rank[r]] += h[r];
+    hp.mark("rank -> id");
     if (logz_sum) *logz_sum = hz;
     m->estep_calls++;
     return cleanup(TGX_OK);

@@ -3,11 +3,68 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <queue>
+#include <thread>
 
 namespace tgx {
 
+static double host_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+HostPhases::HostPhases(const char* scope_) : scope(scope_) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* k = getenv("TGX_KNOBS");
+        const char* e = getenv("TGX_HOST_TIMES");
+        enabled = (k && *k && *k != '0' && e && *e && *e != '0') ? 1 : 0;
+    }
+    on = enabled == 1;
+    t0 = last = on ? host_now() : 0.0;
+}
+void HostPhases::mark(const char* what) {
+    if (!on) return;
+    const double t = host_now();
+    fprintf(stderr, "[tgx host] %-28s %-28s %8.2f ms\n", scope, what, (t - last) * 1e3);
+    last = t;
+}
+HostPhases::~HostPhases() {
+    if (on) fprintf(stderr, "[tgx host] %-28s %-28s %8.2f ms\n", scope, "(total)", (host_now() - t0) * 1e3);
+}
+
 namespace {
+
+// std::sort on `threads` chunks at once, then pairwise std::inplace_merge (the levels' merges at once too): the two big
+// sorts of build_flat_trie (tokens, expansion order) were 67 of its 124 ms at 500 000 tokens
+template <typename It, typename Cmp>
+void parallel_sort(It begin, It end, Cmp cmp) {
+    const size_t n = (size_t)(end - begin);
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t parts = 1;
+    while (parts < 8 && parts * 2 <= (hw ? hw : 1u) && n / (parts * 2) >= 32768) parts *= 2;
+    if (parts == 1) {
+        std::sort(begin, end, cmp);
+        return;
+    }
+    std::vector<size_t> cut(parts + 1);
+    for (size_t i = 0; i <= parts; i++) cut[i] = n * i / parts;
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < parts; i++) th.emplace_back([&, i]() { std::sort(begin + (long)cut[i], begin + (long)cut[i + 1], cmp); });
+        std::sort(begin, begin + (long)cut[1], cmp);
+        for (auto& t : th) t.join();
+    }
+    for (size_t width = 1; width < parts; width *= 2) {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i + width < parts; i += 2 * width) {
+            const size_t a = cut[i], b = cut[i + width], c = cut[std::min(parts, i + 2 * width)];
+            if (i == 0) continue;
+            th.emplace_back([&, a, b, c]() { std::inplace_merge(begin + (long)a, begin + (long)b, begin + (long)c, cmp); });
+        }
+        std::inplace_merge(begin, begin + (long)cut[width], begin + (long)cut[std::min(parts, 2 * width)], cmp);
+        for (auto& t : th) t.join();
+    }
+}
 
 struct Edge {
     uint32_t parent;
@@ -56,6 +113,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
         uint64_t prefix;  // first 8 bytes, big-endian, zero-padded
         uint32_t id;
     };
+    HostPhases hp("build_flat_trie");
     std::vector<Key> order;
     order.reserve(vocab_size);
     uint32_t max_len = 0;
@@ -67,7 +125,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
         order.push_back(Key{k, id});
         max_len = std::max<uint32_t>(max_len, (uint32_t)(e - b));
     }
-    std::sort(order.begin(), order.end(), [&](const Key& x, const Key& y) {
+    parallel_sort(order.begin(), order.end(), [&](const Key& x, const Key& y) {
         if (x.prefix != y.prefix) return x.prefix < y.prefix;
         const uint64_t lx = offs[x.id + 1] - offs[x.id], ly = offs[y.id + 1] - offs[y.id];
         const int c = std::memcmp(bytes + offs[x.id], bytes + offs[y.id], (size_t)std::min(lx, ly));
@@ -75,6 +133,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
         if (lx != ly) return lx < ly;
         return x.id < y.id;
     });
+    hp.mark("sort tokens");
     uint64_t total_bytes = vocab_size ? offs[vocab_size] - offs[0] : 0;
     std::vector<Edge> created;  // in creation (depth-first) order
     created.reserve(total_bytes / 4 + 16);
@@ -101,6 +160,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
         prev_len = len;
     }
     uint32_t n_nodes = (uint32_t)node_tok.size();
+    hp.mark("nodes");
 
     // 2. children in CSR form, sorted by (parent, byte): the children of a node were created in ascending byte
     // order, so a stable counting sort by parent is all it takes.
@@ -129,6 +189,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
         for (const Edge& e : edges) parent[e.child] = e.parent;
         for (uint32_t i = n_nodes; i-- > 1;) weight[parent[i]] += weight[i];  // children are created after parents
     }
+    hp.mark("csr + weights");
     BlockAlloc ba;
     ba.add_block();
     ba.mark(0);  // root
@@ -146,9 +207,10 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
         std::memcpy(&bits, &w, 8);
         keyed[i] = {~bits, i};
     }
-    std::sort(keyed.begin(), keyed.end());
+    parallel_sort(keyed.begin(), keyed.end(), std::less<std::pair<uint64_t, uint32_t>>());
     std::vector<uint32_t> expand(n_nodes);
     for (uint32_t i = 0; i < n_nodes; i++) expand[i] = keyed[i].second;
+    hp.mark("expansion order (sort)");
     uint32_t head1_by_byte[256] = {};  // single-child nodes: first block that may still hold (free slot f, unclaimed base f ^ byte)
     keyed = std::vector<std::pair<uint64_t, uint32_t>>();
     for (uint32_t node : expand) {
@@ -237,6 +299,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
         }
     }
 
+    hp.mark("slot assignment");
     // 4. records.
     uint32_t n_slots = ba.n_blocks() * 256;
     out->table.assign(n_slots, TrieRec{kNoParent, 0, 0});
@@ -261,6 +324,7 @@ void build_flat_trie(const uint8_t* bytes, const uint64_t* offs, const double* s
     }
     out->max_token_len = max_len;
     out->n_nodes = n_nodes;
+    hp.mark("records");
 }
 
 // ---- 8-byte label-checked records + score table (encode5_kernel) ----------------------------------------
@@ -367,26 +431,38 @@ void build_trie8t(const FlatTrie& ft, const uint64_t* offs, const double* scores
     out->id_of_rank.clear();
     out->n_tok = 0;
     if (n_slots > kTrie8TMaxSlots) return;
-    // the tokens that can match (those that own a terminal slot), by descending exp(score) / length; ties by id
+    // the tokens that can match (those that own a terminal slot): the kTrie8TSortedRanks with the largest exp(score) / length
+    // in that order, ties by id; the others follow in id order
     struct Key {
         double weight;
         uint32_t id;
     };
     std::vector<Key> keys;
     keys.reserve(n_slots / 2);
+    std::vector<double> exp_of;  // exp(score) by id: computed once (the weight table below wants the same values)
+    uint32_t id_bound = 0;
     for (uint32_t t = 0; t < n_slots; t++) {
         const uint32_t id = ft.tokid[t];
         if (id == kNoToken) continue;
         const double len = (double)std::max<uint64_t>(1, offs[id + 1] - offs[id]);
-        double w = std::exp(scores[id]) / len;
+        const double e = std::exp(scores[id]);
+        double w = e / len;
         if (!(w == w)) w = 0.0;
         keys.push_back(Key{w, id});
+        id_bound = std::max(id_bound, id + 1u);
+        if (exp_of.size() < (size_t)id + 1) exp_of.resize(std::max<size_t>((size_t)id + 1, exp_of.size() * 2), 0.0);
+        exp_of[id] = e;
     }
     const auto hotter = [](const Key& a, const Key& b) { return a.weight != b.weight ? a.weight > b.weight : a.id < b.id; };
     const size_t head = std::min<size_t>(keys.size(), kTrie8TSortedRanks);
     if (head < keys.size()) {
         std::nth_element(keys.begin(), keys.begin() + (long)head, keys.end(), hotter);
-        std::sort(keys.begin() + (long)head, keys.end(), [](const Key& a, const Key& b) { return a.id < b.id; });
+        // the tail in id order without a sort: mark its ids, then read the marks in order
+        std::vector<uint8_t> in_tail(id_bound, 0);
+        for (size_t i = head; i < keys.size(); i++) in_tail[keys[i].id] = 1;
+        size_t k = head;
+        for (uint32_t id = 0; id < id_bound; id++)
+            if (in_tail[id]) keys[k++] = Key{0.0, id};
     }
     std::sort(keys.begin(), keys.begin() + (long)head, hotter);
     const uint32_t n_tok = (uint32_t)keys.size();
@@ -399,7 +475,7 @@ void build_trie8t(const FlatTrie& ft, const uint64_t* offs, const double* scores
     for (uint32_t r = 0; r < n_tok; r++) {
         rank_of[keys[r].id] = r + 1u;
         out->id_of_rank[r + 1u] = keys[r].id;
-        out->w[r + 1u] = std::exp(scores[keys[r].id]);  // the same function of the same double as the 16-byte tables' weights
+        out->w[r + 1u] = exp_of[keys[r].id];  // std::exp(score): the same function of the same double as the 16-byte tables' weights
     }
     out->rec.assign(n_slots, Trie8TRec{0, 0});
     for (uint32_t t = 0; t < n_slots; t++) {

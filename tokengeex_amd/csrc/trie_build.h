@@ -18,6 +18,17 @@
 
 namespace tgx {
 
+// Wall time of host phases to stderr when TGX_KNOBS=1 TGX_HOST_TIMES=1 (tools/prune_bench.py): where a prune iteration's
+// host time goes.  mark("x") prints the time since the previous mark (or construction).
+struct HostPhases {
+    const char* scope;
+    bool on;
+    double t0, last;
+    explicit HostPhases(const char* scope_);
+    void mark(const char* what);
+    ~HostPhases();
+};
+
 struct TrieRec {
     uint32_t check;
     uint32_t base;  // bit 31: terminal
@@ -83,7 +94,9 @@ uint64_t trie8_common_prefix_search(const Trie8& t8, const FlatTrie& ft, const u
                                     uint32_t* lens, uint64_t cap);
 
 // Records of estep7_kernel (estep7.hip) over the SAME slot assignment: {base | label << 24, rank of the token that ends
-// here (0: none)}.  The child by byte c of a node is the record at byte offset 8 * ((rec ^ c) & 0xFFFFFF), valid iff its
+// here (0: none)}.  (The order below is the one build_trie8t leaves; tgx_api.cpp re-ranks by MEASURED match counts at the
+// model's first E-step — round 4 also tried the probability mass of the tokens below a token's node as the proxy for how
+// often it matches: worse than exp(score) / length for both this table and encode5's value table.)  The child by byte c of a node is the record at byte offset 8 * ((rec ^ c) & 0xFFFFFF), valid iff its
 // label is c (exact for the reasons given above; 2^24 slots).  Tokens are ranked by exp(score) / length — how often they
 // are expected to match — because the first ranks' weights and expected-count sums live in the blocks' LDS; only the
 // first `sorted_ranks` ranks are in that order (the kernels never keep more in LDS), the others follow in id order.

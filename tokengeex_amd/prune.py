@@ -87,11 +87,17 @@ class ModelVocabularyPruner:
         toks, scores, keep = arrays
         V = len(toks)
         pruned_size = max(int(V * self.shrink_factor), self.vocab_size)
+        t0 = time.perf_counter()
         always_keep, alt_offs, alt_ids = model.prune_alternatives()  # over the model's own table
+        t1 = time.perf_counter()
         freq = tdist.allreduce_vector(model.count_tokens(corpus), self.dist, self.reduce_device)
         n_samples = tdist.allreduce_scalar(corpus.num_samples, self.dist, self.reduce_device)
+        t2 = time.perf_counter()
         out = np.asarray(_lib.prune_select(freq, keep, always_keep, alt_offs, alt_ids, scores, n_samples, pruned_size), np.int64)
-        return toks.take(out), scores[out], keep[out]
+        t3 = time.perf_counter()
+        res = toks.take(out), scores[out], keep[out]
+        self.last_prune_phases = {"alternatives_s": t1 - t0, "count_tokens_s": t2 - t1, "select_s": t3 - t2, "take_s": time.perf_counter() - t3}
+        return res
 
     def prune_vocab(self, vocab: Vocab, model: _lib.NativeModel, corpus: _lib.NativeCorpus) -> Vocab:
         """src/prune.rs:173-319."""
@@ -104,10 +110,12 @@ class ModelVocabularyPruner:
         arrays = self._arrays(vocab)
         try:
             while len(arrays[0]) > self.vocab_size:
-                rec = {"from": len(arrays[0]), "e_step_s": 0.0, "m_step_s": 0.0}
+                rec = {"from": len(arrays[0]), "model_s": 0.0, "e_step_s": 0.0, "m_step_s": 0.0, "derive_s": 0.0}
+                t_iter = time.perf_counter()
                 # one double-array build per iteration: the models of the later sub-iterations and of the pruning step
                 # are subsets of the first one's vocabulary and live on its tables (tgx_model_create_derived)
                 model = self._model(arrays, for_estep=True)
+                rec["model_s"] = time.perf_counter() - t_iter
                 for sub in range(self.em_subiters):
                     t0 = time.perf_counter()
                     expected = self.run_e_step(model, corpus)
@@ -122,11 +130,14 @@ class ModelVocabularyPruner:
                     model.free()
                     model = nxt
                     arrays = new_arrays
+                    rec["derive_s"] += time.perf_counter() - t2
                 t0 = time.perf_counter()
                 arrays = self._prune_arrays(arrays, model, corpus)
                 rec["prune_vocab_s"] = time.perf_counter() - t0
+                rec["prune_vocab_phases"] = getattr(self, "last_prune_phases", None)
                 rec["to"] = len(arrays[0])
                 model.free()
+                rec["wall_s"] = time.perf_counter() - t_iter
                 self.timings.append(rec)
                 self.log(f"pruned vocabulary from={rec['from']} to={rec['to']}")
             vocab = self._vocab(*arrays)

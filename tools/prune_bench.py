@@ -19,6 +19,8 @@ assert len(toks) == V, (len(toks), V)
 flat, offs = synth.make_corpus(size << 20, "mixed", seed_offset=1000)
 vocab = [(t, float(s), len(t) == 1) for t, s in zip(toks, scores)]
 p = ModelVocabularyPruner(target, 0.75, 2, 0.01, log=lambda m: print(m, file=sys.stderr, flush=True))
+import tokengeex_amd as tgx
+tgx.NativeModel(toks[:300], scores[:300]).free()  # (the device context, the first hipMalloc: not part of a prune run's rate)
 t0 = time.perf_counter()
 out = p.prune(vocab, flat, offs)
 wall = time.perf_counter() - t0
