@@ -209,6 +209,9 @@ __device__ __forceinline__ void relax4_step(double sv, double& acc, uint32_t& bp
 // comparison only steers the winner bookkeeping, off the chain that the next step waits for:
 // broadcast -> add -> max instead of broadcast -> add -> compare -> mask OR -> two selects.  Same count of
 // VALU instructions, about a third of the latency per position (a lone 64 KiB sample: 7.1 -> ms per pass).
+// (Round 4 removed two of the step's nine vector instructions as an experiment — no `fhi`, the reset by the high word
+// alone with a finite sentinel: 150 of the kernel's 1 252 static VALU instructions gone, ids still bit-exact, 12.60 ->
+// 12.66 ms per GiB.  The vector ALU is 79 % busy but it is not what the pass waits for: profiles/r04.)
 template <int U>
 __device__ __forceinline__ void relax5_step(double sv, double& acc, uint32_t& bpv, uint32_t& fin, uint32_t& fhi) {
     constexpr uint64_t MU = kRowLane0 << U;  // lanes with l == U
