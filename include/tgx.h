@@ -324,6 +324,9 @@ uint64_t tgx_last_estep_redo(const tgx_model *m);
 /* CUs the long-sample kernel had to itself while encode5_kernel ran on the others in the last encode pass
  * (batches of a few hundred MB whose longest samples bound either kernel alone); 0: the kernels ran one after the other. */
 uint32_t tgx_last_encode_corun_cus(const tgx_model *m);
+/* co-run passes of this model whose host-side wait for the resident blocks of encode5_kernel ran into its 2 ms limit
+ * (0 in a healthy setup; after the first one the model launches its two encode kernels one after the other). */
+uint32_t tgx_encode_corun_timeouts(const tgx_model *m);
 /* distinct score values of the vocabulary as the rows5 encode kernels rank them (0: the model has no 8-byte
  * records — tokens longer than 16 bytes, non-finite scores, more than 65 535 distinct values — or has not
  * encoded yet when it was created for E-step passes), and how many of them the last encode5_kernel launch

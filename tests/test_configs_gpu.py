@@ -140,6 +140,7 @@ def test_default_decisions_by_batch_size_on_the_spec_vocabulary():
             assert "encode6_kernel" in kt and nat.last_encode_long_samples() > 0 and nat.last_encode_corun_cus() == 0
         elif want == "corun":
             assert "encode6_kernel" in kt and "encode5_kernel" in kt and nat.last_encode_corun_cus() > 0
+            assert nat.encode_corun_timeouts() == 0  # the host saw encode5_kernel's blocks report themselves within the limit
             assert 0 < nat.last_encode_long_samples() < offs.size - 1
         else:
             assert "encode6_kernel" not in kt and nat.last_encode_corun_cus() == 0

@@ -347,6 +347,30 @@ def test_token_end_mask_pipeline(monkeypatch, max_len):
     assert _enc(nat2, [b"abba", b"", b"b"]) == [[0, 1, 1, 0], [], [1]]
 
 
+@pytest.mark.parametrize("carry", ["0", "1"])
+@pytest.mark.parametrize("max_len", [16, 24])
+def test_trace_keeps_or_flushes_its_waiting_tokens(monkeypatch, max_len, carry):
+    """trace_kernel / trace32_kernel in both modes (trace_body.h): tokens that wait for their lookup carry over from one sample
+    to the next (TGX_TRACE_CARRY=1: the default for samples of less than 2 KiB on average) or are flushed per sample; on a
+    corpus of short samples with empty ones in between and on one of long samples, ids and offsets against the oracle."""
+    monkeypatch.setenv("TGX_TRACE_CARRY", carry)
+    rng = np.random.default_rng(500 + max_len)
+    flat, offs = synth.make_corpus(384 << 10, "mixed", seed_offset=61 + max_len, max_len=180)
+    if max_len == 16:
+        toks, scores = synth.build_vocab(flat[: 256 << 10], 3000, 16)
+    else:
+        toks, scores = synth.random_vocab(rng, bytes(flat[: 96 << 10]), n_multi=4000, max_len=max_len, tie_fraction=0.5)
+    nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
+    assert_same_encoding(nat, ora, flat, offs)
+    assert ("trace_kernel" if max_len == 16 else "trace32_kernel") in nat.last_kernel_times()
+    texts = [b"", b"a", b"", b"ab" * 16, b"", b"", b"q" * 63, b"q" * 64, b"q" * 65, b""] + [bytes(flat[i * 97: i * 97 + n]) for i, n in enumerate(range(1, 150))]
+    f2, o2 = tgx.pack(texts)
+    assert_same_encoding(nat, ora, f2, o2)
+    assert_same_encoding(nat, ora, f2, o2, dropout=0.2, seed=3)
+    f3, o3 = synth.make_corpus(256 << 10, "mixed", seed_offset=5, max_len=30000)
+    assert_same_encoding(nat, ora, f3, o3)
+
+
 def test_long_token_overflow_redoes_only_the_samples_concerned():
     """Every position of "aaaa..." matches sixteen tokens of 17..32 bytes: far more than a wave's overflow list
     holds, so the samples of such a wave are redone by encode2_kernel (and only those: the batch also has

@@ -95,6 +95,7 @@ SYMBOLS = {
     "tgx_last_estep_pieces": (_u64, [_vp]),
     "tgx_last_estep_redo": (_u64, [_vp]),
     "tgx_last_encode_corun_cus": (_u32, [_vp]),
+    "tgx_encode_corun_timeouts": (_u32, [_vp]),
 }
 
 
@@ -593,6 +594,9 @@ class NativeModel:
 
     def last_encode_corun_cus(self) -> int:
         return lib.tgx_last_encode_corun_cus(self._h)
+
+    def encode_corun_timeouts(self) -> int:
+        return lib.tgx_encode_corun_timeouts(self._h)
 
 
 class FlatTrie:

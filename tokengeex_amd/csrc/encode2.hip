@@ -201,10 +201,10 @@ __global__ __launch_bounds__(640) void encode2_kernel(EncodeParams P) {
 
 // trace_kernel (kernels.hip) for tokens of up to 32 bytes (trace_body.h).
 // PERM: the back-pointer bytes are in encode4_kernel's permuted layout (bp8_perm; encode4l_kernel), else plain
-template <bool PERM>
+template <bool PERM, bool CARRY>
 __global__ __launch_bounds__(256) void trace32_kernel(EncodeParams P) {
-    __shared__ uint2 ring_all[4][kTraceRing];
-    trace_body<32, PERM, false>(P, ring_all[threadIdx.x >> 6]);
+    __shared__ typename TraceRingEntry<CARRY>::type ring_all[4][kTraceRing];
+    trace_body<32, PERM, false, CARRY>(P, ring_all[threadIdx.x >> 6]);
 }
 
 // two blocks of five waves per CU: 10 x 16 KiB of LDS
@@ -220,10 +220,9 @@ hipError_t launch_encode2(const EncodeParams& p, uint32_t num_cus, bool permuted
     return hipGetLastError();
 }
 hipError_t launch_trace32(const EncodeParams& p, uint32_t blocks, bool permuted, hipStream_t stream) {
-    if (permuted)
-        hipLaunchKernelGGL(trace32_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL(trace32_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
+    auto fn = permuted ? (p.trace_carry ? trace32_kernel<true, true> : trace32_kernel<true, false>)
+                       : (p.trace_carry ? trace32_kernel<false, true> : trace32_kernel<false, false>);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

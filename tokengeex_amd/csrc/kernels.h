@@ -34,6 +34,7 @@ struct EncodeParams {
     // round 4 (trace2.hip): ids in their final place
     unsigned long long* endmask;    // u64[mask_words + 1]: sample s owns words mword[s] .. mword[s + 1); bit j of its word k = "a token ends
                                     // with the sample's byte 64 k + j" (every word is written by mark_kernel; the last is padding, 0)
+    uint32_t trace_carry;           // trace kernels: waiting tokens carry over from sample to sample (short samples: trace_body.h)
     const uint64_t* mword;          // u64[S + 1]: exclusive scan of ceil(n / 64) over the samples
     uint64_t mask_words;            // mword[S]
     const uint64_t* prefix;         // u64[mask_words + 1]: set bits before each word (launch_mask_scan)

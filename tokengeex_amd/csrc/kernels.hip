@@ -599,10 +599,10 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 6 : 1)) void encode4_kernel(Encod
 }
 
 // Back-trace + id emission for the rows4 path (trace_body.h).
-template <bool STAMP>
+template <bool STAMP, bool CARRY>
 __global__ __launch_bounds__(256) void trace_kernel(EncodeParams P) {
-    __shared__ uint2 ring_all[4][kTraceRing];
-    trace_body<16, true, STAMP>(P, ring_all[threadIdx.x >> 6]);
+    __shared__ typename TraceRingEntry<CARRY>::type ring_all[4][kTraceRing];
+    trace_body<16, true, STAMP, CARRY>(P, ring_all[threadIdx.x >> 6]);
 }
 
 // counts[S] -> offsets[S+1] (exclusive prefix sum), one workgroup.
@@ -754,9 +754,11 @@ hipError_t launch_encode4(const EncodeParams& p, int ppl, int waves, uint32_t bl
 }
 hipError_t launch_trace(const EncodeParams& p, uint32_t blocks, hipStream_t stream) {
     if (p.stamps)
-        hipLaunchKernelGGL(trace_kernel<true>, dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, p);
+    else if (p.trace_carry)
+        hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL(trace_kernel<false>, dim3(blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -199,6 +199,7 @@ struct tgx_model {
     uint64_t last_long_samples = 0;    // samples the last pass gave a block of their own (encode6_kernel)
     uint64_t last_estep_pieces = 0;    // pieces the last E-step cut its snippets into (0: uncut)
     uint32_t last_corun_cus = 0;       // CUs the long-sample kernel had to itself beside encode5_kernel in the last pass (0: one after the other)
+    uint32_t corun_wait_timeouts = 0;  // co-run passes whose host wait for encode5_kernel's blocks ran into its 2 ms limit (then: no more co-runs)
     uint64_t last_redo_samples = 0;    // samples the last encode4l pass left to encode2_kernel
     bool mask_path = false;            // the last encode pass wrote the token-end mask (TGX_TRACE=mask: mark / scan / emit, trace2.hip)
     int last_encode_waves_per_cu = 0;  // resident waves per CU of the last rows4 encode launch (self-check)
@@ -410,6 +411,10 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
     p.queue = m->d_ctrl;
     p.dropout = dropout;
     p.seed = seed;
+    // samples of less than 2 KiB on average: the trace keeps its waiting tokens across samples (trace_body.h; 140-byte samples
+    // 5.5 -> 4.6 ms per GiB, 9 KiB samples 2.93 -> 3.04)
+    p.trace_carry = (c->n_samples && c->n_bytes / c->n_samples < 2048) ? 1u : 0u;
+    if (const char* e = knob("TGX_TRACE_CARRY")) p.trace_carry = atoi(e) ? 1u : 0u;
     p.endmask = c->d_endmask;
     p.mword = c->d_mword;
     p.mask_words = c->mask_words;
@@ -531,7 +536,9 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 static const uint32_t shares[] = {32, 48, 64, 96, 128, 160, 192};
                 // (only when encode5_kernel keeps every value in LDS on its few waves: its COLD builds are bound by the
                 // chains of mid-length samples at twice the estimate — profiles/r03/p_corun_sweep*.txt)
-                const bool corun_off = (knob("TGX_CORUN") && atoi(knob("TGX_CORUN")) == 0) ||
+                // (and never again after a pass whose host wait for encode5_kernel's blocks timed out: the device's atomic to
+                // mapped host memory was not delivered, every co-run would pay the full 2 ms and lose the CU separation)
+                const bool corun_off = (knob("TGX_CORUN") && atoi(knob("TGX_CORUN")) == 0) || m->corun_wait_timeouts != 0 ||
                                        m->n_values > tgx::encode5_max_hot(false, 8, 4, 160u * 1024u);
                 for (uint64_t thr : thrs) {
                     if (corun_off || thr > c->max_len || e6_bpc != 2) break;
@@ -735,8 +742,10 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 // until every one of those has reported itself resident
                 const auto t0 = std::chrono::steady_clock::now();
                 volatile unsigned int* started = m->h_started;
-                while (*started < blocks5 && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2)) {
+                bool timed_out = false;
+                while (*started < blocks5 && !(timed_out = std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(2))) {
                 }
+                if (timed_out && *started < blocks5) m->corun_wait_timeouts++;
             }
             const hipError_t l6 = tgx::launch_encode6(p6, q6, cold6, blocks6, m->stream2);
             if (slot) (void)hipEventRecord(m->timed[m->n_timed + 1].stop, m->stream2);
@@ -3307,6 +3316,7 @@ uint64_t tgx_last_encode_long_samples(const tgx_model* m) { return m ? m->last_l
 uint64_t tgx_last_estep_pieces(const tgx_model* m) { return m ? m->last_estep_pieces : 0; }
 uint64_t tgx_last_estep_redo(const tgx_model* m) { return m ? m->last_estep_redo : 0; }
 uint32_t tgx_last_encode_corun_cus(const tgx_model* m) { return m ? m->last_corun_cus : 0; }
+uint32_t tgx_encode_corun_timeouts(const tgx_model* m) { return m ? m->corun_wait_timeouts : 0; }
 uint32_t tgx_model_score_values(const tgx_model* m) { return m && m->have_trie8 ? m->n_values : 0u; }
 uint32_t tgx_last_encode_hot_values(const tgx_model* m) { return m ? m->last_n_hot : 0u; }
 
