@@ -145,3 +145,38 @@ def test_default_decisions_by_batch_size_on_the_spec_vocabulary():
         else:
             assert "encode6_kernel" not in kt and nat.last_encode_corun_cus() == 0
             assert nat.last_encode_waves_per_cu() <= 10 and nat.last_encode_hot_values() == nat.score_values()
+
+
+def test_the_cost_model_picks_a_near_best_launch(monkeypatch):
+    """run_encode_kernel (tgx_api.cpp) chooses between the long-sample kernel, both encode kernels at once and
+    encode5_kernel alone from constants measured once (bytes per second of each kernel, seconds per byte of a chain).
+    This is the check that they still hold on the box at hand: at every size the default must be within 15 % of the best
+    of the forced alternatives (no long-sample kernel; the long-sample kernel without co-run), best of five passes each —
+    a drifted constant shows up as a default that loses to an alternative."""
+    import time
+    toks, scores, _ = synth.load_spec_vocab(32000)
+    nat = tgx.NativeModel(toks, scores)
+
+    def best_ms(corpus, reps=5):
+        nat.encode_corpus(corpus).free()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            nat.encode_corpus(corpus).free()
+            ts.append(time.perf_counter() - t)
+        return min(ts) * 1e3
+
+    for mib in (64, 256, 512):
+        flat, offs = synth.make_corpus(mib << 20, "mixed", seed_offset=1000)
+        corpus = tgx.NativeCorpus(flat, offs)
+        t_default = best_ms(corpus)
+        alts = {}
+        monkeypatch.setenv("TGX_LONG_THRESHOLD", str(1 << 30))  # no sample is "long": encode5_kernel alone
+        alts["encode5 alone"] = best_ms(corpus)
+        monkeypatch.delenv("TGX_LONG_THRESHOLD")
+        monkeypatch.setenv("TGX_CORUN", "0")                    # the long-sample kernel first, then encode5_kernel
+        alts["no co-run"] = best_ms(corpus)
+        monkeypatch.delenv("TGX_CORUN")
+        corpus.free()
+        best = min(alts.values())
+        assert t_default <= 1.15 * best, (mib, t_default, alts)
