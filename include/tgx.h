@@ -115,6 +115,12 @@ tgx_status tgx_split_specials(const uint8_t *text, const uint64_t *offs, uint64_
 tgx_status tgx_pack_segments(const uint8_t *text, const uint64_t *seg_begin, const uint64_t *seg_end,
                              const int32_t *seg_special, uint64_t n, int crlf, uint8_t *out_text,
                              uint64_t *out_offs, uint64_t *n_out);
+/* UnicodeProcessor::preprocess (src/processor.rs:124-137) over packed segments: form 0 NFD, 1 NFC, 2 NFKD, 3 NFKC (UAX #15;
+ * tables of Unicode tgx_unidata_version()).  Bytes that are not UTF-8 pass through unchanged.  out_text / out_offs are
+ * malloc'd (tgx_free): n_segs segments back to back, offsets u64[n_segs + 1]. */
+tgx_status tgx_normalize_segments(uint32_t form, const uint8_t *text, const uint64_t *seg_begin, const uint64_t *seg_end,
+                                  uint64_t n_segs, uint8_t **out_text, uint64_t **out_offs);
+const char *tgx_unidata_version(void);
 tgx_status tgx_assemble_ids(const uint64_t *seg_offs, const int32_t *seg_special, uint64_t n_samples,
                             const uint32_t *ids, const uint64_t *id_offs, uint32_t vocab_size,
                             uint32_t *out_ids, uint64_t *out_offs);

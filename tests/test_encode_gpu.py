@@ -563,6 +563,30 @@ def test_native_front_end_equals_the_per_sample_python_path(monkeypatch):
     assert got[-1] == [base + 3] and got[-6] == [base + 0] and got[-5] == [base + 0, base + 0]
 
 
+@pytest.mark.parametrize("procs", [("nfc",), ("crlf", "nfkc"), ("nfd", "crlf")])
+def test_native_front_end_with_unicode_processors(monkeypatch, procs):
+    """The Unicode normalisation forms of src/processor.rs:124-137 on packed buffers (csrc/unicode_norm.cpp), alone and in
+    either order with the CRLF processor (src/tokenizer.rs:79-82 applies the list in order, per segment between special
+    tokens): encode_batch / encode_ordinary_batch equal the per-segment Python path (unicodedata)."""
+    flat, offs, toks, scores = corpus_and_vocab(1 << 20, "mixed", 3000, 16, seed_offset=33, max_len=3000)
+    vocab = [(t, float(s), len(t) == 1) for t, s in zip(toks, scores)]
+    specials = ["<EOS>", "é", "\n\n\n"]
+    tk = tgx.Tokenizer(vocab, [tgx.CrlfProcessor() if p == "crlf" else tgx.UnicodeProcessor(p) for p in procs], specials)
+    raw = flat.tobytes()
+    texts = []
+    for i in range(min(300, offs.size - 1)):
+        t = raw[int(offs[i]):int(offs[i + 1])].decode("utf-8", "ignore")
+        if i % 3 == 0:
+            t = t[: len(t) // 2] + "e\u0301 \ufb01 \u212b\r\n" + specials[i % 3] + "\uac01\u1100\u1161" + t[len(t) // 2:]
+        texts.append(t)
+    texts += ["", "e\u0301", "\u0301", "<EOS>\u0301", "a\r\n\u0301"]
+    got = tk.encode_batch(texts, 0.0)
+    got_ord = tk.encode_ordinary_batch(texts, 0.0)
+    monkeypatch.setattr(tgx.Tokenizer, "_native_front", lambda self: False)
+    assert got == tk.encode_batch(texts, 0.0)
+    assert got_ord == tk.encode_ordinary_batch(texts, 0.0)
+
+
 def test_host_to_host_entry_point_chunks_and_errors(monkeypatch):
     """tgx_encode_batch_host: the batch in chunks through upload / kernels / download on three host threads —
     same ids and offsets as the one-piece path whatever the chunk size, the lowest failing sample reported,

@@ -69,6 +69,8 @@ SYMBOLS = {
     "tgx_estep": (_i, [_vp, _vp, _u64, _d, _u64, _vp, C.POINTER(C.c_double)]),
     "tgx_split_specials": (_i, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _pvp, _pvp, _pvp, _pu64]),
     "tgx_pack_segments": (_i, [_vp, _vp, _vp, _vp, _u64, _i, _vp, _vp, _pu64]),
+    "tgx_normalize_segments": (_i, [_u32, _vp, _vp, _vp, _u64, _pvp, _pvp]),
+    "tgx_unidata_version": (C.c_char_p, []),
     "tgx_assemble_ids": (_i, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp]),
     "tgx_decode_batch": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u64, _i, _pvp, _vp, _pu64, _pu64]),
     "tgx_utf8_lossy": (_u64, [_vp, _u64, _vp]),
@@ -257,6 +259,26 @@ def pack_segments(flat: np.ndarray, seg_begin: np.ndarray, seg_end: np.ndarray, 
                                 C.byref(m)))
     out_offs = out_offs[: m.value + 1]
     return out[: int(out_offs[-1])], out_offs
+
+
+NORMAL_FORMS = {"nfd": 0, "nfc": 1, "nfkd": 2, "nfkc": 3}
+
+
+def normalize_flat(form: str, flat: np.ndarray, offs: np.ndarray):
+    """UnicodeProcessor::preprocess over a packed batch (src/processor.rs:124-137) -> (flat, offs), native (csrc/unicode_norm.cpp)."""
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    n = offs.shape[0] - 1
+    beg, end = np.ascontiguousarray(offs[:-1]), np.ascontiguousarray(offs[1:])
+    ot, oo = C.c_void_p(), C.c_void_p()
+    check(lib.tgx_normalize_segments(NORMAL_FORMS[form], ptr(flat) if flat.size else None, ptr(beg) if n else None, ptr(end) if n else None, n,
+                                     C.byref(ot), C.byref(oo)))
+    out_offs = _take(oo, n + 1, C.c_uint64, np.uint64)
+    return _take(ot, int(out_offs[-1]), C.c_uint8, np.uint8), out_offs
+
+
+def unidata_version() -> str:
+    return lib.tgx_unidata_version().decode()
 
 
 def assemble_ids(seg_offs: np.ndarray, seg_special: np.ndarray, ids: np.ndarray, id_offs: np.ndarray, vocab_size: int):

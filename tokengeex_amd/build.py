@@ -15,8 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtgx.so")
-SOURCES = ["kernels.hip", "estep.hip", "encode2.hip", "encode4l.hip", "encode5.hip", "estep4.hip", "estep4l.hip", "estep7.hip", "trace2.hip", "cuts.hip", "pairs.hip", "generate.hip", "tgx_api.cpp", "trie_build.cpp", "prune_host.cpp", "frontback.cpp"]
-HEADERS = ["kernels.h", "device_common.h", "trace_body.h", "trie_build.h", os.path.join("..", "..", "include", "tgx.h")]
+SOURCES = ["kernels.hip", "estep.hip", "encode2.hip", "encode4l.hip", "encode5.hip", "estep4.hip", "estep4l.hip", "estep7.hip", "trace2.hip", "cuts.hip", "pairs.hip", "generate.hip", "tgx_api.cpp", "trie_build.cpp", "prune_host.cpp", "frontback.cpp", "unicode_norm.cpp"]
+HEADERS = ["kernels.h", "device_common.h", "trace_body.h", "trie_build.h", "unicode_tables.h", os.path.join("..", "..", "include", "tgx.h")]
 ARCH = "gfx950"
 
 

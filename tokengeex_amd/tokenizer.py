@@ -144,9 +144,19 @@ class Tokenizer:
         return self.encode_ordinary_batch([text], dropout)[0]
 
     def _native_front(self) -> bool:
-        """The packed-buffer front end (csrc/frontback.cpp) covers the CRLF processor; a Unicode
-        normalisation form (unicodedata) keeps the per-segment Python path."""
-        return all(isinstance(p, CrlfProcessor) for p in self._processors)
+        """The packed-buffer front end covers both processors of the reference (src/processor.rs): CRLF (csrc/frontback.cpp)
+        and, from round 4, the Unicode normalisation forms (csrc/unicode_norm.cpp; `unicodedata` stays as the checker of the
+        tests and in UnicodeProcessor.preprocess for single strings)."""
+        return all(isinstance(p, (CrlfProcessor, UnicodeProcessor)) for p in self._processors)
+
+    def _preprocess_flat(self, flat: np.ndarray, offs: np.ndarray):
+        """The processors, in order (src/tokenizer.rs:79-82), over a packed batch of segments."""
+        for p in self._processors:
+            if isinstance(p, CrlfProcessor):
+                flat, offs = _lib.pack_segments(flat, np.ascontiguousarray(offs[:-1]), np.ascontiguousarray(offs[1:]), None, True)
+            else:
+                flat, offs = _lib.normalize_flat(p.form, flat, offs)
+        return flat, offs
 
     def _rows_native(self, texts: list[str], dropout: float, ordinary: bool) -> list[list[int]]:
         """list[str] -> list[list[int]] with both ends in native code (csrc/pyfast.c; bindings/python/src/lib.rs:51-69 builds
@@ -173,18 +183,20 @@ class Tokenizer:
         offsets[S+1]) -> (ids uint32[T], offsets uint64[S+1]): special-token split, CRLF processor, encode and
         the assembly of the ids all run on packed buffers in native code (src/tokenizer.rs:65-123)."""
         if not self._native_front():
-            raise TokenGeeXError("encode_batch_flat: only the CRLF processor runs on packed buffers", _lib.ERR_UNSUPPORTED)
+            raise TokenGeeXError("encode_batch_flat: a processor without a packed-buffer form", _lib.ERR_UNSUPPORTED)
         flat = np.ascontiguousarray(flat, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
-        crlf = len(self._processors) > 0
+        only_crlf = all(isinstance(p, CrlfProcessor) for p in self._processors)  # then the packing pass does it on the way
+        crlf = only_crlf and len(self._processors) > 0
         n = offs.shape[0] - 1
         if ordinary or not self._special_tokens:
-            if crlf:
-                beg, end = np.ascontiguousarray(offs[:-1]), np.ascontiguousarray(offs[1:])
-                flat, offs = _lib.pack_segments(flat, beg, end, None, True)
+            if n and self._processors:
+                flat, offs = self._preprocess_flat(flat, offs)
             return self.encode_ordinary_batch_flat(flat, offs, dropout) if n else (np.zeros(0, np.uint32), np.zeros(1, np.uint64))
         seg_offs, sb, se, ss = _lib.split_specials_flat(flat, offs, [t.encode("utf-8") for t in self._special_tokens])
         pflat, poffs = _lib.pack_segments(flat, sb, se, ss, crlf)
+        if not only_crlf and poffs.shape[0] > 1:
+            pflat, poffs = self._preprocess_flat(pflat, poffs)
         if poffs.shape[0] > 1:
             ids, id_offs = self.encode_ordinary_batch_flat(pflat, poffs, dropout)
         else:
