@@ -29,5 +29,8 @@ python tools/prune_bench.py 256 500000 375000 > $O/prune_256MiB_500k_vocab.json 
 python tools/prune_bench.py 256 32000 16000 > $O/prune_256MiB.json 2>/dev/null
 python tools/merge_bench.py 256 32000 300 100 16 > $O/merge_256MiB.json 2>/dev/null
 python tools/e6_shapes.py > $O/e6_shapes.txt 2>&1
+TGX_KNOBS=1 python tools/e7_derived.py 256 short > $O/estep_second_subiteration_500k.txt 2>&1
+TGX_KNOBS=1 TGX_HOST_TIMES=1 python tools/prune_bench.py 256 500000 375000 > /dev/null 2> $O/prune_500k_host_phases.txt
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 python tests/measure/cpu_port_threads.py > $O/config0_cpu_port_threads.json 2>/dev/null
 ls -la $O
