@@ -1206,6 +1206,11 @@ tgx_status tgx_model_create_derived(const tgx_model* parent, const uint32_t* kee
     const uint32_t PV = parent->vocab_size;
     for (uint32_t i = 0; i < n_keep; i++)
         if (keep_ids[i] >= PV || (i && keep_ids[i] <= keep_ids[i - 1])) return fail(TGX_ERR_INVALID, "tgx_model_create_derived: keep_ids must ascend within the parent's vocabulary");
+    // A derived model keeps the parent's slot count.  A parent above the 8-byte records' limit would leave the model that
+    // `prune` encodes with (its frequency pass) on the 16-byte kernels however small the vocabulary has become: such a
+    // model is built from scratch (the caller does that on TGX_ERR_UNSUPPORTED), its own table is within the limit sooner.
+    if (!(flags & TGX_MODEL_FOR_ESTEP) && parent->flat.table.size() > tgx::kTrie8MaxSlots && (uint64_t)n_keep * 2 <= PV)
+        return fail(TGX_ERR_UNSUPPORTED, "tgx_model_create_derived: the parent's table has more slots than 8-byte records address; build this model from scratch");
     {   // every non-empty token of the parent must own a terminal slot
         uint64_t non_empty = 0, terminals = 0;
         for (uint32_t i = 0; i < PV; i++) non_empty += parent->vocab_offs[i + 1] > parent->vocab_offs[i];
