@@ -544,3 +544,33 @@ def test_estep7_after_an_m_step_ranks_by_match_counts(monkeypatch):
     small = tgx.NativeModel(toks2, sc2, for_estep=True)
     got3, _ = small.estep(corpus, 81920, 0.05, 4)
     np.testing.assert_allclose(got3, got, rtol=1e-9, atol=ATOL)
+
+
+def test_estep7_overflow_build_for_vocabularies_of_a_few_more_than_65535_tokens(monkeypatch):
+    """16-bit match entries hold 65 535 ranks; a vocabulary of up to 1 024 more tokens (the usual "64 K": the committed
+    65 536-entry spec vocabulary) keeps them and hands the trips in which a token of a rank beyond matches to the redo
+    kernel, which then has 32-bit entries (tgx_api.cpp estep_fused, estep7.hip OVF).  Against the oracle: the spec
+    vocabulary as it is, and a small vocabulary whose ranks beyond 1 500 / 40 are treated that way (TGX_E7_OVF_AT), so
+    that a large share of the trips takes the path — with dropout, with the model's own rank order and with a tiny table."""
+    toks, scores, _ = synth.load_spec_vocab(65536)
+    assert len(toks) == 65536
+    nat, ora = _pair(toks, scores)
+    flat, offs = synth.make_corpus(3 << 20, "mixed", seed_offset=88)
+    _check_estep(nat, ora, flat, offs)
+    kt = nat.last_kernel_times()
+    assert "estep7_kernel" in kt
+    _check_estep(nat, ora, flat, offs, dropout=0.1, seed=5)
+    # a small vocabulary, many overflow matches
+    f2, o2 = synth.make_corpus(2 << 20, "mixed", seed_offset=89)
+    t2, s2 = synth.build_vocab(f2[: 1 << 20], 4000, 16)
+    ora2 = orc.OracleModel(t2, s2)
+    for at, extra in (("1500", {}), ("40", {"TGX_E7_HOT": "20"}), ("1500", {"TGX_E7_RANK": "model"})):
+        monkeypatch.setenv("TGX_E7_OVF_AT", at)
+        for k, v in extra.items():
+            monkeypatch.setenv(k, v)
+        nat2 = tgx.NativeModel(t2, s2, for_estep=True)
+        _check_estep(nat2, ora2, f2, o2)
+        assert "estep7_kernel" in nat2.last_kernel_times() and nat2.last_estep_redo() > 100
+        _check_estep(nat2, ora2, f2, o2, dropout=0.2, seed=9)
+        for k in extra:
+            monkeypatch.delenv(k)

@@ -63,12 +63,14 @@ struct Walk7Ctx {
 // The PPL staggered walks of a lane (encode5.hip: Walk5) over records {base | label << 24, token rank}: the child by byte
 // c of a node is the record at byte offset 8 ((rec ^ c) & 0xFFFFFF), valid iff its label is c.  A match stores its
 // token's rank at (start, length) of the group's entry buffer and is the walk's longest so far.
-template <bool DROPOUT, bool WIDE, int PPL, int D>
+// OVF (16-bit entries for a vocabulary of a few more than 65 535 tokens): `seen` collects the ranks of the matches — a rank
+// beyond the entries' range shows there after the walk and the trip is handed to the redo kernel (32-bit entries).
+template <bool DROPOUT, bool WIDE, int PPL, int D, bool OVF = false>
 struct Walk7 {
     using L = E7Lay<WIDE>;
     static __device__ __forceinline__ void run(const Walk7Ctx& W, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
                                                const uint32_t (&pgh)[PPL], const uint32_t (&wlane)[PPL], bool (&alive)[PPL],
-                                               uint2 (&rec)[PPL], uint32_t (&c)[PPL], uint32_t (&mlen)[PPL]) {
+                                               uint2 (&rec)[PPL], uint32_t (&c)[PPL], uint32_t (&mlen)[PPL], uint32_t& seen) {
         bool any = false;
 #pragma unroll
         for (int g = 0; g < PPL; ++g) {
@@ -82,6 +84,7 @@ struct Walk7 {
             if (term) {
                 lds_st<typename L::ET>(wlane[g] | ((W.lcs + L::CS * (uint32_t)D) & (15u * L::CS)), (typename L::ET)tok);
                 mlen[g] = (uint32_t)D + 1u;
+                if (OVF) seen = max(seen, tok);
             }
             if (D + 1 < 16) {
                 constexpr int e = D + 1 < 16 ? D + 1 : 15;
@@ -95,13 +98,13 @@ struct Walk7 {
             any = any || alive[g];
         }
         if (__builtin_amdgcn_ballot_w64(any) == 0) return;
-        Walk7<DROPOUT, WIDE, PPL, D + 1>::run(W, bytes, maxd, pgh, wlane, alive, rec, c, mlen);
+        Walk7<DROPOUT, WIDE, PPL, D + 1, OVF>::run(W, bytes, maxd, pgh, wlane, alive, rec, c, mlen, seen);
     }
 };
-template <bool DROPOUT, bool WIDE, int PPL>
-struct Walk7<DROPOUT, WIDE, PPL, 16> {
+template <bool DROPOUT, bool WIDE, int PPL, bool OVF>
+struct Walk7<DROPOUT, WIDE, PPL, 16, OVF> {
     static __device__ __forceinline__ void run(const Walk7Ctx&, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL], const uint32_t (&)[PPL],
-                                               const uint32_t (&)[PPL], bool (&)[PPL], uint2 (&)[PPL], uint32_t (&)[PPL], uint32_t (&)[PPL]) {}
+                                               const uint32_t (&)[PPL], bool (&)[PPL], uint2 (&)[PPL], uint32_t (&)[PPL], uint32_t (&)[PPL], uint32_t&) {}
 };
 
 // A match entry in registers is the LDS byte offset `ha` = 16 * rank of its token's {sum, w} (entry 0 = {0, 0}: "no
@@ -291,7 +294,7 @@ __device__ __forceinline__ void e7_weights(__amdgpu_buffer_rsrc_t wtab, uint32_t
 #define E7_STAMP(i)
 #endif
 
-template <bool DROPOUT, bool COLD, bool WIDE, int PPL>
+template <bool DROPOUT, bool COLD, bool WIDE, int PPL, bool OVF = false>
 __global__ __launch_bounds__(768) void estep7_kernel(Estep7Params P) {
     using L = E7Lay<WIDE>;
     using ET = typename L::ET;
@@ -422,7 +425,17 @@ __global__ __launch_bounds__(768) void estep7_kernel(Estep7Params P) {
             uint32_t lcs = l * L::CS;
             asm volatile("" : "+v"(lcs));
             Walk7Ctx W{trie_b, smp, lcs, P.dropout, P.seed};
-            Walk7<DROPOUT, WIDE, PPL, 0>::run(W, bytes, maxd, pgh, wlane, alive, rec, c, mlen);
+            uint32_t seen = 0;
+            Walk7<DROPOUT, WIDE, PPL, 0, OVF>::run(W, bytes, maxd, pgh, wlane, alive, rec, c, mlen, seen);
+            if (OVF) {
+                // a match whose rank the 16-bit entries cannot hold (one of the vocabulary's least matched tokens): the stretch
+                // from here to the next cut goes to the redo kernel, exactly as a stretch without a cut does
+                const uint64_t ob = __builtin_amdgcn_ballot_w64(seen > P.ovf_limit);
+                if (live && !probe && ((ob >> (16u * r)) & 0xFFFFull) != 0ull) {
+                    probe = true;
+                    redo_p0 = p0;
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
         E7_STAMP(1)  // text window, reset, walk
@@ -704,7 +717,8 @@ __global__ __launch_bounds__(256) void estep7_redo_kernel(Estep7RedoParams P) {
                 uint32_t lcs = l * L::CS;
                 asm volatile("" : "+v"(lcs));
                 Walk7Ctx W{trie_b, smp, lcs, P.dropout, P.seed};
-                Walk7<DROPOUT, WIDE, 1, 0>::run(W, bytes, maxd, pgh, wlane, alive, rec, c, mlen);
+                uint32_t seen_unused = 0;
+                Walk7<DROPOUT, WIDE, 1, 0>::run(W, bytes, maxd, pgh, wlane, alive, rec, c, mlen, seen_unused);
             }
             __builtin_amdgcn_wave_barrier();
             uint32_t ha[16];
@@ -833,7 +847,8 @@ hipError_t launch_estep7_redo(Estep7RedoParams p, bool wide, uint32_t num_cus, h
 }
 
 typedef void (*estep7_fn)(Estep7Params);
-static estep7_fn pick_estep7(bool dropout, bool cold, bool wide, int ppl) {
+static estep7_fn pick_estep7(bool dropout, bool cold, bool wide, int ppl, bool ovf = false) {
+    if (ovf) return dropout ? estep7_kernel<true, true, false, 4, true> : estep7_kernel<false, true, false, 4, true>;  // (cold, 16-bit entries, four positions per lane)
 #define TGX_E7P(D, C, W) (ppl == 1 ? estep7_kernel<D, C, W, 1> : ppl == 2 ? estep7_kernel<D, C, W, 2> : ppl == 3 ? estep7_kernel<D, C, W, 3> : estep7_kernel<D, C, W, 4>)
 #define TGX_E7W(D, C) (wide ? TGX_E7P(D, C, true) : TGX_E7P(D, C, false))
     if (dropout) return cold ? TGX_E7W(true, true) : TGX_E7W(true, false);
@@ -916,12 +931,15 @@ hipError_t estep7_waves_per_simd(bool dropout, bool cold, bool wide, int ppl, in
     *out = regs > 0 ? (512 / regs > 8 ? 8 : 512 / regs) : 8;
     return hipSuccess;
 }
+// p.ovf_limit < n_tok (and !wide): the overflow build — ranks beyond ovf_limit (<= 65 535) are left to the redo kernel
 hipError_t launch_estep7(Estep7Params p, bool wide, int ppl, int waves, uint32_t blocks, hipStream_t stream) {
     const bool cold = p.n_hot < p.n_tok;
+    const bool ovf = !wide && p.ovf_limit < p.n_tok;
     const uint32_t lds = estep7_lds_layout(p.n_hot, wide, waves, ppl, &p.root_off, &p.zero_off, &p.idx_off);
-    if (lds > 160u * 1024u || p.n_hot > p.n_tok || ppl < 1 || ppl > 4 || waves < 1 || waves > 12 || (!wide && p.n_tok > 65535u)) return hipErrorInvalidValue;
+    if (lds > 160u * 1024u || p.n_hot > p.n_tok || ppl < 1 || ppl > 4 || waves < 1 || waves > 12 || (!wide && !ovf && p.n_tok > 65535u)) return hipErrorInvalidValue;
+    if (ovf && (p.ovf_limit > 65535u || ppl != 4 || !cold)) return hipErrorInvalidValue;
     if (!p.work) return hipErrorInvalidValue;
-    estep7_fn fn = pick_estep7(p.dropout > 0.0, cold, wide, ppl);
+    estep7_fn fn = pick_estep7(p.dropout > 0.0, cold, wide, ppl, ovf);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipMemcpyAsync(const_cast<Estep7Work*>(p.work), &p.host_work, sizeof(Estep7Work), hipMemcpyHostToDevice, stream);

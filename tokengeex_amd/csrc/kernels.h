@@ -199,6 +199,7 @@ struct Estep7Params {
     uint32_t root_base;
     const double* wtab;             // f64[n_tok + 1]: [0] = 0, [r] = exp(score of the token of rank r)
     uint32_t n_tok;                 // tokens that can match (ranks 1 .. n_tok)
+    uint32_t ovf_limit;             // 16-bit builds: a match of a rank beyond it sends its trip to the redo kernel (0xFFFFFFFF: none can occur)
     uint32_t n_hot;                 // ranks 1 .. n_hot have {sum, w} in the block's LDS
     double* expected;               // f64[n_tok + 1] expected counts by rank
     double dropout;

@@ -2656,14 +2656,29 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         }
     }
     const uint64_t units = pieces ? pc.n : K;
-    const bool wide = m->n_tok7 > 65535u;
+    // 16-bit match entries hold 65 535 ranks.  A vocabulary of a few more tokens (the usual "64 K": 65 536) keeps them — 34
+    // against 24 GB/s with 32-bit entries — and leaves the trips in which one of its least matched tokens (the ranks beyond
+    // 65 535: the tokens are ranked by match counts) matches to the redo kernel, which has 32-bit entries then.
+    // TGX_E7_OVF_AT=<rank> (tests) makes the ranks beyond <rank> such tokens.
+    uint32_t ovf_limit = 0xFFFFFFFFu;
+    if (m->n_tok7 > 65535u && m->n_tok7 <= 65535u + 1024u) ovf_limit = 65535u;
+    if (const char* e = knob("TGX_E7_OVF_AT")) {
+        const long v = atol(e);
+        if (v >= 1 && v <= 65535 && m->n_tok7 <= 65535u + 1024u) ovf_limit = (uint32_t)v;
+        if (v == 0) ovf_limit = 0xFFFFFFFFu;
+    }
+    bool ovf = ovf_limit < m->n_tok7;
+    const bool wide = m->n_tok7 > 65535u && !ovf;
+    const bool wide_redo = wide || ovf;
     // (1 GiB, 32 000 entries: 12 waves x 4 positions per lane 32.5 ms, 10 waves 36.2, 8 waves 41.7; three positions per lane
     // 34.2 / 38.5 / 44.3 and forty times the stretches without a cut in a trip — profiles/r04)
     int ppl = wide ? 2 : 4, waves = 12;
+    const bool ppl_forced = ovf;  // (the overflow build exists for four positions per lane)
     if (const char* e = knob("TGX_EPPL")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 4) ppl = v;
     }
+    if (ppl_forced) ppl = 4;
     if (const char* e = knob("TGX_E7_WAVES")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 12) waves = v;
@@ -2679,6 +2694,7 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         const int v = atoi(e);
         if (v >= 0) n_hot = std::min(n_hot, (uint32_t)v);
     }
+    if (ovf && n_hot >= m->n_tok7) n_hot = m->n_tok7 - 1u;  // (the overflow build is a COLD build)
     const size_t ebytes = ((size_t)m->n_tok7 + 1) * 8 + 256, zbytes = (size_t)K * 8 + 256;
     // (the redo list: a piece can leave several stretches, each longer than a trip's reach)
     const uint64_t redo_cap = units + N / 32 + 16;
@@ -2726,6 +2742,7 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     p.wtab = m->d_wtab;
     p.n_tok = m->n_tok7;
     p.n_hot = n_hot;
+    p.ovf_limit = ovf ? ovf_limit : 0xFFFFFFFFu;
     p.expected = d_exp;
     wk.zsnip = d_zsnip;
     wk.logz_sum = d_z;
@@ -2798,7 +2815,7 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
             tbase[i + 1] = tbase[i] + (ro[2 * i + 1] - ro[2 * i]) / 16 + 1;
         }
         const uint64_t TT = tbase[n_redo];
-        const size_t rs = wide ? 1024 : 512;
+        const size_t rs = wide_redo ? 1024 : 512;
         const size_t ab = (size_t)TT * 16 * 8 + 256, xb = (size_t)TT * 4 + 256, mb = (size_t)TT * rs + 256, tbb = (size_t)(n_redo + 1) * 8 + 256;
         double* d_alpha = nullptr;
         int32_t* d_aexp = nullptr;
@@ -2831,7 +2848,7 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         q.root_base = p.root_base;
         q.wtab = m->d_wtab;
         q.n_tok = m->n_tok7;
-        q.n_hot = std::min(std::min(m->n_tok7, tgx::estep7_redo_max_hot(wide)), n_hot);
+        q.n_hot = std::min(std::min(m->n_tok7, tgx::estep7_redo_max_hot(wide_redo)), n_hot);
         q.expected = d_exp;
         q.zsnip = d_zsnip;
         q.logz_sum = d_z;
@@ -2843,7 +2860,7 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
         q.dropout = dropout;
         q.seed = seed;
         time_begin(m, "estep7_redo_kernel");
-        const hipError_t le = tgx::launch_estep7_redo(q, wide, (uint32_t)m->num_cus, m->stream);
+        const hipError_t le = tgx::launch_estep7_redo(q, wide_redo, (uint32_t)m->num_cus, m->stream);
         time_end(m);
         if (le != hipSuccess) return cleanup(cleanup2(fail(TGX_ERR_DEVICE, "estep7 redo launch failed: %s", hipGetErrorString(le))));
         if (hipMemcpyAsync(&flag, m->d_ctrl + 5, 8, hipMemcpyDeviceToHost, m->stream) != hipSuccess)
