@@ -44,8 +44,18 @@ for case in range(cases):
     flat, offs = tgx.pack(texts)
     dropout = float(rng.choice([0.0, 0.0, 0.1, 0.5, 1.0]))
     sd = int(rng.integers(0, 1 << 62))
-    for k in ("TGX_PPL", "TGX_EPPL", "TGX_PATH", "TGX_LONG_THRESHOLD", "TGX_E5_HOT", "TGX_E6_POOL", "TGX_E2E_CHUNK_MB", "TGX_ESTEP_PIECES", "TGX_ESTEP_WINDOW", "TGX_CORUN"):
+    for k in ("TGX_PPL", "TGX_EPPL", "TGX_PATH", "TGX_LONG_THRESHOLD", "TGX_E5_HOT", "TGX_E6_POOL", "TGX_E2E_CHUNK_MB", "TGX_ESTEP_PIECES", "TGX_ESTEP_WINDOW", "TGX_CORUN",
+              "TGX_TRACE", "TGX_TRACE_CARRY", "TGX_E7_HOT", "TGX_E7_WAVES", "TGX_E7_RANK", "TGX_E7_OVF_AT", "TGX_ESTEP"):
         os.environ.pop(k, None)
+    # round 4: the trace's two modes and the mask pipeline; estep7_kernel's table size, waves, rank order, overflow build;
+    # the chained kernels now and then
+    if rng.random() < 0.5: os.environ["TGX_TRACE_CARRY"] = str(int(rng.choice([0, 1])))
+    if rng.random() < 0.2: os.environ["TGX_TRACE"] = "mask"
+    if rng.random() < 0.4: os.environ["TGX_E7_HOT"] = str(int(rng.choice([0, 5, 60, 700])))
+    if rng.random() < 0.3: os.environ["TGX_E7_WAVES"] = str(int(rng.choice([1, 3, 8])))
+    if rng.random() < 0.3: os.environ["TGX_E7_RANK"] = "model"
+    if rng.random() < 0.3: os.environ["TGX_E7_OVF_AT"] = str(int(rng.choice([3, 50, 400, 2000])))
+    if rng.random() < 0.15: os.environ["TGX_ESTEP"] = "chain"
     if rng.random() < 0.6: os.environ["TGX_PPL"] = str(int(rng.choice([1, 2, 4])))
     if rng.random() < 0.6: os.environ["TGX_EPPL"] = str(int(rng.choice([1, 2, 4])))
     # round 2: kernel choice (encode5 / encode4), long-sample kernel threshold, score table size (cold values
@@ -61,7 +71,7 @@ for case in range(cases):
         os.environ["TGX_ESTEP_PIECES"] = "1"
         os.environ["TGX_ESTEP_WINDOW"] = str(int(rng.choice([256, 512, 2048])))
     nat, ora = tgx.NativeModel(toks, scores), orc.OracleModel(toks, scores)
-    tag = f"case {case} max_len={max_len} all_bytes={all_bytes} V={len(toks)} S={len(texts)} N={flat.size} dropout={dropout} env={os.environ.get('TGX_PPL')}/{os.environ.get('TGX_EPPL')}/{os.environ.get('TGX_PATH')}/{os.environ.get('TGX_LONG_THRESHOLD')}/{os.environ.get('TGX_E5_HOT')}/{os.environ.get('TGX_E6_POOL')}/{os.environ.get('TGX_ESTEP_PIECES')}/{os.environ.get('TGX_ESTEP_WINDOW')}/{os.environ.get('TGX_CORUN')}"
+    tag = f"case {case} max_len={max_len} all_bytes={all_bytes} V={len(toks)} S={len(texts)} N={flat.size} dropout={dropout} env={os.environ.get('TGX_PPL')}/{os.environ.get('TGX_EPPL')}/{os.environ.get('TGX_PATH')}/{os.environ.get('TGX_LONG_THRESHOLD')}/{os.environ.get('TGX_E5_HOT')}/{os.environ.get('TGX_E6_POOL')}/{os.environ.get('TGX_ESTEP_PIECES')}/{os.environ.get('TGX_ESTEP_WINDOW')}/{os.environ.get('TGX_CORUN')} r4={os.environ.get('TGX_TRACE_CARRY')}/{os.environ.get('TGX_TRACE')}/{os.environ.get('TGX_E7_HOT')}/{os.environ.get('TGX_E7_WAVES')}/{os.environ.get('TGX_E7_RANK')}/{os.environ.get('TGX_E7_OVF_AT')}/{os.environ.get('TGX_ESTEP')}"
     try:
         want_ids, want_offs = ora.encode_batch_flat(flat, offs, dropout, sd, threads=8)
         want_err = None
