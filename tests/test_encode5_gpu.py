@@ -221,3 +221,37 @@ def test_long_and_short_samples_at_once(monkeypatch, cus):
     monkeypatch.setenv("TGX_CORUN", "0")
     assert_same_encoding(nat, ora, flat, offs)
     assert nat.last_encode_corun_cus() == 0
+
+
+def test_values_reranked_by_match_counts_after_an_m_step(monkeypatch):
+    """A vocabulary as an M-step leaves it (src/prune.rs:124-170: one value per token, kept single-byte tokens with tiny
+    scores that still match everywhere): encode5_kernel's values are re-ranked by how often a sample of the first corpus
+    reads them (tgx_api.cpp ensure_value_ranks).  Ids must not depend on the order: bit-exact against the oracle with the
+    re-ranked values, with build_trie8's order (TGX_VALUE_RANK=model), with dropout, on a second corpus, and after an
+    E-step on the chained kernels rewrote the tables."""
+    from tokengeex_amd import _lib
+    flat, offs = synth.make_corpus(6 << 20, "mixed", seed_offset=71)
+    toks, scores = synth.build_vocab(flat[: 2 << 20], 30000, 16)
+    base = tgx.NativeModel(toks, scores, for_estep=True)
+    exp, _ = base.estep(tgx.NativeCorpus(flat, offs))
+    keep = np.array([1 if len(t) == 1 else 0 for t in toks], np.uint8)
+    idx, sc2 = _lib.prune_m_step(exp, keep)
+    idx, sc2 = np.asarray(idx, np.int64), np.asarray(sc2, np.float64)
+    toks2 = [toks[i] for i in idx]
+    assert len(set(sc2.tolist())) > 9000  # more values than LDS holds: the COLD build
+    ora = orc.OracleModel(toks2, sc2)
+    monkeypatch.setenv("TGX_E5_HOT", "2000")  # (a batch this small would get a table that holds every value)
+    nat = tgx.NativeModel(toks2, sc2)
+    assert_same_encoding(nat, ora, flat, offs)
+    kt = nat.last_kernel_times()
+    assert "encode5_kernel" in kt and 0 < nat.last_encode_hot_values() < nat.score_values()
+    assert_same_encoding(nat, ora, flat, offs, dropout=0.1, seed=3)
+    f2, o2 = synth.make_corpus(1 << 20, "mixed", seed_offset=72, max_len=3000)
+    assert_same_encoding(nat, ora, f2, o2)
+    monkeypatch.setenv("TGX_ESTEP", "chain")  # the chained E-step kernels rewrite the 8-byte records and the value tables
+    got, _ = nat.estep(tgx.NativeCorpus(f2, o2))
+    monkeypatch.delenv("TGX_ESTEP")
+    assert_same_encoding(nat, ora, f2, o2)
+    monkeypatch.setenv("TGX_VALUE_RANK", "model")
+    plain = tgx.NativeModel(toks2, sc2)
+    assert_same_encoding(plain, ora, flat, offs)

@@ -901,6 +901,36 @@ __global__ __launch_bounds__(256) void match_count_kernel(const uint8_t* __restr
     for (uint32_t i = threadIdx.x; i < kCountLds; i += blockDim.x)
         if (hist[i] && i <= n_tok) atomicAdd(&counts[i], hist[i]);
 }
+// the same count over encode5_kernel's records {8 base | label << 24, rank of the SCORE VALUE}: how often every value is read
+__global__ __launch_bounds__(256) void value_count_kernel(const uint8_t* __restrict__ text, uint64_t n_bytes, uint32_t chunk, uint64_t stride,
+                                                          const uint2* __restrict__ trie, uint32_t n_slots, uint32_t root_base, uint32_t n_values,
+                                                          uint32_t max_len, unsigned int* __restrict__ counts) {
+    __shared__ unsigned int hist[kCountLds];
+    for (uint32_t i = threadIdx.x; i < kCountLds; i += blockDim.x) hist[i] = 0u;
+    __syncthreads();
+    const uint64_t n_chunks = (n_bytes + stride - 1) / stride;
+    const uint64_t total = n_chunks * chunk;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = (i / chunk) * stride + (i % chunk);
+        if (p >= n_bytes) continue;
+        const uint32_t reach = (uint32_t)(n_bytes - p < max_len ? n_bytes - p : max_len);
+        uint32_t t = root_base ^ text[p];
+        for (uint32_t k = 0; k < reach; ++k) {
+            if (t >= n_slots) break;
+            const uint2 rec = trie[t];
+            if ((rec.x >> 24) != text[p + k]) break;
+            const uint32_t rank = rec.y & 0xFFFFu;
+            if (rank) {
+                if (rank < kCountLds) atomicAdd(&hist[rank], 1u);
+                else if (rank <= n_values) atomicAdd(&counts[rank], 1u);
+            }
+            if (k + 1u < reach) t = ((rec.x ^ ((uint32_t)text[p + k + 1u] << 3)) & 0xFFFFFFu) >> 3;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kCountLds; i += blockDim.x)
+        if (hist[i] && i <= n_values) atomicAdd(&counts[i], hist[i]);
+}
 __global__ __launch_bounds__(256) void rank_remap_kernel(uint2* __restrict__ trie, uint32_t n_slots, const uint32_t* __restrict__ perm) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_slots) return;
@@ -912,6 +942,13 @@ hipError_t launch_match_count(const uint8_t* text, uint64_t n_bytes, uint32_t ch
     if (!n_bytes || !chunk || stride < chunk) return hipErrorInvalidValue;
     hipLaunchKernelGGL(match_count_kernel, dim3(num_cus * 4u), dim3(256), 0, stream, text, n_bytes, chunk, stride,
                        reinterpret_cast<const uint2*>(trie8t), n_slots, root_base, n_tok, counts);
+    return hipGetLastError();
+}
+hipError_t launch_value_count(const uint8_t* text, uint64_t n_bytes, uint32_t chunk, uint64_t stride, const void* trie8, uint32_t n_slots,
+                              uint32_t root_base, uint32_t n_values, uint32_t max_len, unsigned int* counts, uint32_t num_cus, hipStream_t stream) {
+    if (!n_bytes || !chunk || stride < chunk) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(value_count_kernel, dim3(num_cus * 4u), dim3(256), 0, stream, text, n_bytes, chunk, stride,
+                       reinterpret_cast<const uint2*>(trie8), n_slots, root_base, n_values, max_len, counts);
     return hipGetLastError();
 }
 hipError_t launch_rank_remap(void* trie8t, uint32_t n_slots, const uint32_t* perm, hipStream_t stream) {

@@ -245,7 +245,10 @@ hipError_t launch_estep7(Estep7Params p, bool wide, int ppl, int waves, uint32_t
 // once per match, whatever its score: the ranks that stay in LDS are chosen by these counts (tgx_api.cpp).
 hipError_t launch_match_count(const uint8_t* text, uint64_t n_bytes, uint32_t chunk, uint64_t stride, const void* trie8t, uint32_t n_slots,
                               uint32_t root_base, uint32_t n_tok, unsigned int* counts, uint32_t num_cus, hipStream_t stream);
-// rec[t].tok = perm[rec[t].tok] for every slot of the 8-byte E-step records
+// the same over encode5_kernel's records: counts[rank of the score value] (walks of up to max_len bytes)
+hipError_t launch_value_count(const uint8_t* text, uint64_t n_bytes, uint32_t chunk, uint64_t stride, const void* trie8, uint32_t n_slots,
+                              uint32_t root_base, uint32_t n_values, uint32_t max_len, unsigned int* counts, uint32_t num_cus, hipStream_t stream);
+// rec[t].tok = perm[rec[t].tok] for every slot of the 8-byte E-step records (and encode5_kernel's: the second word is the rank there too)
 hipError_t launch_rank_remap(void* trie8t, uint32_t n_slots, const uint32_t* perm, hipStream_t stream);
 hipError_t launch_snip_z_check(const double* zsnip, uint64_t n_snips, unsigned long long* err_snip, hipStream_t stream);
 hipError_t launch_piece_z_add(const double* zarr, const uint32_t* psnip, const uint32_t* order, uint64_t n_order, double* zsnip, hipStream_t stream);

@@ -199,6 +199,7 @@ struct tgx_model {
     uint64_t last_long_samples = 0;    // samples the last pass gave a block of their own (encode6_kernel)
     uint64_t last_estep_pieces = 0;    // pieces the last E-step cut its snippets into (0: uncut)
     uint32_t last_corun_cus = 0;       // CUs the long-sample kernel had to itself beside encode5_kernel in the last pass (0: one after the other)
+    bool values_ranked = false;        // the score values were re-ranked by how often a sample of some corpus reads them (ensure_value_ranks)
     uint32_t corun_wait_timeouts = 0;  // co-run passes whose host wait for encode5_kernel's blocks ran into its 2 ms limit (then: no more co-runs)
     uint64_t last_redo_samples = 0;    // samples the last encode4l pass left to encode2_kernel
     bool mask_path = false;            // the last encode pass wrote the token-end mask (TGX_TRACE=mask: mark / scan / emit, trace2.hip)
@@ -377,6 +378,80 @@ uint32_t grid_blocks(const tgx_model* m, uint64_t n_samples) {
     return (uint32_t)std::max<uint64_t>(1, std::min(want, cap));
 }
 
+// encode5_kernel keeps the first ranks of the score values in LDS.  build_trie8 ranks a value by the probability mass of
+// its tokens — how often they are CHOSEN — but a value is read whenever one of its tokens MATCHES: a vocabulary after an
+// M-step has a value per token, and its kept single-byte tokens have tiny scores and match at every position.  So, as
+// for the E-step's ranks (ensure_estep_trie8t), the first time a model with more values than fit LDS meets text the
+// values are re-ranked by match counts over a sample of it (value_count_kernel, 4 MiB): the records' ranks are remapped on
+// the device, the value table(s) permuted.  Caller holds m->mu.
+tgx_status ensure_value_ranks(tgx_model* m, const tgx_corpus* c) {
+    if (m->values_ranked || !m->have_trie8 || !c->n_bytes) return TGX_OK;
+    m->values_ranked = true;
+    if (m->n_values <= tgx::encode5_max_hot(false, 13, 3, 160u * 1024u)) return TGX_OK;  // (every value in LDS anyway)
+    if (const char* e = knob("TGX_VALUE_RANK")) {
+        if (strcmp(e, "model") == 0) return TGX_OK;  // keep build_trie8's order (measurements, tests)
+    }
+    tgx::HostPhases hp("ensure_value_ranks");
+    HIP_TRY(hipSetDevice(m->device));
+    const uint32_t nv = m->n_values, chunk = 65536u;
+    const uint64_t stride = std::max<uint64_t>(chunk, (c->n_bytes + 63) / 64);
+    const size_t cb = ((size_t)nv + 1) * 4 + 256;
+    unsigned int* d_cnt = nullptr;
+    uint32_t* d_perm = nullptr;
+    auto drop = [&]() {
+        pool_free(m->device, d_cnt, cb);
+        pool_free(m->device, d_perm, cb);
+    };
+    if (pool_alloc(m->device, cb, (void**)&d_cnt) != hipSuccess || pool_alloc(m->device, cb, (void**)&d_perm) != hipSuccess) {
+        drop();
+        return fail(TGX_ERR_DEVICE, "out of device memory (value counts)");
+    }
+    std::vector<unsigned int> cnt((size_t)nv + 1, 0u);
+    std::vector<double> values((size_t)nv + 1), wvalues;
+    bool ok = hipMemsetAsync(d_cnt, 0, cb, m->stream) == hipSuccess &&
+              tgx::launch_value_count(c->d_text, c->n_bytes, chunk, stride, m->d_trie8, (uint32_t)m->flat.table.size(), m->root_base8, nv,
+                                      std::max<uint32_t>(1, m->flat.max_token_len), d_cnt, (uint32_t)m->num_cus, m->stream) == hipSuccess &&
+              hipMemcpyAsync(cnt.data(), d_cnt, ((size_t)nv + 1) * 4, hipMemcpyDeviceToHost, m->stream) == hipSuccess &&
+              hipMemcpyAsync(values.data(), m->d_values, ((size_t)nv + 1) * 8, hipMemcpyDeviceToHost, m->stream) == hipSuccess;
+    if (ok && m->have_wvalues) {
+        wvalues.resize((size_t)nv + 1);
+        ok = hipMemcpyAsync(wvalues.data(), m->d_wvalues, ((size_t)nv + 1) * 8, hipMemcpyDeviceToHost, m->stream) == hipSuccess;
+    }
+    if (!ok || hipStreamSynchronize(m->stream) != hipSuccess) {
+        drop();
+        return fail(TGX_ERR_DEVICE, "value count pass failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    hp.mark("value counts");
+    std::vector<uint32_t> order(nv);
+    for (uint32_t r = 0; r < nv; r++) order[r] = r + 1u;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });  // ties: the old order
+    std::vector<uint32_t> perm((size_t)nv + 1, 0u);
+    std::vector<double> v2((size_t)nv + 1), w2(wvalues.size());
+    v2[0] = values[0];
+    if (!w2.empty()) w2[0] = wvalues[0];
+    unsigned long long total = 0, run = 0;
+    for (uint32_t r = 0; r < nv; r++) total += cnt[order[r]];
+    std::vector<double> cov((size_t)nv + 1, 0.0);
+    for (uint32_t r = 0; r < nv; r++) {
+        perm[order[r]] = r + 1u;
+        v2[r + 1u] = values[order[r]];
+        if (!w2.empty()) w2[r + 1u] = wvalues[order[r]];
+        run += cnt[order[r]];
+        cov[r + 1u] = total ? (double)run / (double)total : 1.0;
+    }
+    cov[nv] = 1.0;
+    ok = hipMemcpyAsync(d_perm, perm.data(), ((size_t)nv + 1) * 4, hipMemcpyHostToDevice, m->stream) == hipSuccess &&
+         tgx::launch_rank_remap(m->d_trie8, (uint32_t)m->flat.table.size(), d_perm, m->stream) == hipSuccess &&
+         hipMemcpyAsync(m->d_values, v2.data(), ((size_t)nv + 1) * 8, hipMemcpyHostToDevice, m->stream) == hipSuccess &&
+         (w2.empty() || hipMemcpyAsync(m->d_wvalues, w2.data(), ((size_t)nv + 1) * 8, hipMemcpyHostToDevice, m->stream) == hipSuccess) &&
+         hipStreamSynchronize(m->stream) == hipSuccess;
+    drop();
+    if (!ok) return fail(TGX_ERR_DEVICE, "value re-rank failed: %s", hipGetErrorString(hipGetLastError()));
+    m->value_coverage = std::move(cov);
+    hp.mark("re-rank");
+    return TGX_OK;
+}
+
 // Runs the wave-per-sample kernel over the corpus; on return (stream synced)
 // h_ctrl[0] = min failing sample (~0 if none).
 tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64_t seed) {
@@ -444,6 +519,10 @@ tgx_status run_encode_kernel(tgx_model* m, tgx_corpus* c, double dropout, uint64
                 (unsigned long long)c->n_samples, (unsigned long long)c->n_bytes, p.lm, use4 ? (use5 ? "rows5" : "rows4") : (use2 ? "rows2" : "fused"),
                 m->flat.table.size(), p.root_base, m->n_values);
     if (use5) {
+        {
+            const tgx_status rst = ensure_value_ranks(m, c);
+            if (rst != TGX_OK) return rst;
+        }
         // One block of sixteen waves per CU, and the block's LDS (160 KiB) is shared by the match-index buffers (2 KiB
         // per wave and 16 positions per lane) and the copy of the hottest score values.  Three geometries, by the
         // number of distinct score values (1 GiB of the bench corpus, profiles/r03):
@@ -2324,7 +2403,8 @@ static tgx_status ensure_estep_trie8(tgx_model* m) {
     HIP_TRY(hipMemcpy(m->d_wvalues, w.data(), nv * 8, hipMemcpyHostToDevice));
     m->n_values = (uint32_t)nv - 1u;
     m->root_base8 = t8.root_base;
-    if (m->value_coverage.empty()) m->value_coverage = std::move(t8.coverage);
+    if (m->values_ranked || m->value_coverage.empty()) m->value_coverage = std::move(t8.coverage);
+    m->values_ranked = false;  // (the tables just written are in build_trie8's order again: the next encode re-ranks them)
     m->have_wvalues = true;
     return TGX_OK;
 }
