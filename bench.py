@@ -210,6 +210,30 @@ def main() -> None:
         if rank == 0 and not args.no_cpu_baseline:
             estep["cpu_baseline"] = cpu_baseline_estep(toks, scores, flat, offs, me, min(args.cpu_seconds, 10.0))
         me.free()
+        # ---- encode with the vocabulary an M-step makes of these expected counts (src/prune.rs:124-170: one score per token,
+        # kept single-byte tokens with tiny scores): what `prune` encodes with; reported as `mstep_vocab_mb_s`, never as `value`
+        if not args.no_distinct:
+            from tokengeex_amd import _lib as _tl
+            keep = np.array([1 if len(t) == 1 else 0 for t in toks], np.uint8)
+            idx, sc3 = _tl.prune_m_step(expected, keep)
+            idx, sc3 = np.asarray(idx, np.int64), np.asarray(sc3, np.float64)
+            m3 = tgx.NativeModel([toks[i] for i in idx], sc3, device=dev)
+            for _ in range(max(1, args.warmup)):
+                m3.encode_corpus(corpus).free()
+            sync_all()
+            t4 = time.perf_counter()
+            k4: dict[str, float] = {}
+            for _ in range(args.steps):
+                m3.encode_corpus(corpus).free()
+                for k, v in m3.last_kernel_times().items():
+                    k4[k] = k4.get(k, 0.0) + v
+            sync_all()
+            e4 = time.perf_counter() - t4
+            mx4, tb4, _ = tdist.aggregate_timing(e4, n_bytes, 0, dist, coll_dev)
+            estep["mstep_vocab_mb_s"] = round(tb4 * max(1, args.steps) / mx4 / 1e6, 2)
+            estep["mstep_vocab"] = {"tokens": int(idx.size), "score_values": m3.score_values(), "lds_score_values": m3.last_encode_hot_values(),
+                                    "kernel_ms_per_step": {k: round(v / max(1, args.steps), 3) for k, v in k4.items()}}
+            m3.free()
 
     # ---- PCIe-inclusive rate of the host-buffer entry point (tgx_encode_batch + copies of ids and offsets
     # into caller memory), rank 0 only, after the timed region.  Reported as `e2e_mb_s`, never as `value`.
