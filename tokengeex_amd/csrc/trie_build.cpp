@@ -66,6 +66,21 @@ void parallel_sort(It begin, It end, Cmp cmp) {
     }
 }
 
+// fn(begin, end) over [0, n) in contiguous ranges on up to 8 host threads (ranges of at least `grain`)
+template <typename Fn>
+void parallel_ranges(size_t n, size_t grain, Fn fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t parts = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1u), (size_t)8, n / std::max<size_t>(grain, 1) + 1}));
+    if (parts == 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < parts; i++) th.emplace_back([&, i]() { fn(n * i / parts, n * (i + 1) / parts); });
+    fn((size_t)0, n / parts);
+    for (auto& t : th) t.join();
+}
+
 struct Edge {
     uint32_t parent;
     uint32_t child;
@@ -439,20 +454,25 @@ void build_trie8t(const FlatTrie& ft, const uint64_t* offs, const double* scores
     };
     std::vector<Key> keys;
     keys.reserve(n_slots / 2);
-    std::vector<double> exp_of;  // exp(score) by id: computed once (the weight table below wants the same values)
     uint32_t id_bound = 0;
     for (uint32_t t = 0; t < n_slots; t++) {
         const uint32_t id = ft.tokid[t];
         if (id == kNoToken) continue;
-        const double len = (double)std::max<uint64_t>(1, offs[id + 1] - offs[id]);
-        const double e = std::exp(scores[id]);
-        double w = e / len;
-        if (!(w == w)) w = 0.0;
-        keys.push_back(Key{w, id});
+        keys.push_back(Key{0.0, id});
         id_bound = std::max(id_bound, id + 1u);
-        if (exp_of.size() < (size_t)id + 1) exp_of.resize(std::max<size_t>((size_t)id + 1, exp_of.size() * 2), 0.0);
-        exp_of[id] = e;
     }
+    std::vector<double> exp_of(id_bound, 0.0);  // exp(score) by id: computed once (the weight table below wants the same values)
+    parallel_ranges(keys.size(), 32768, [&](size_t a, size_t b) {  // (half a million exp: 8 of this function's 17 ms on one thread)
+        for (size_t i = a; i < b; i++) {
+            const uint32_t id = keys[i].id;
+            const double len = (double)std::max<uint64_t>(1, offs[id + 1] - offs[id]);
+            const double e = std::exp(scores[id]);
+            double w = e / len;
+            if (!(w == w)) w = 0.0;
+            keys[i].weight = w;
+            exp_of[id] = e;
+        }
+    });
     const auto hotter = [](const Key& a, const Key& b) { return a.weight != b.weight ? a.weight > b.weight : a.id < b.id; };
     const size_t head = std::min<size_t>(keys.size(), kTrie8TSortedRanks);
     if (head < keys.size()) {
@@ -478,7 +498,8 @@ void build_trie8t(const FlatTrie& ft, const uint64_t* offs, const double* scores
         out->w[r + 1u] = exp_of[keys[r].id];  // std::exp(score): the same function of the same double as the 16-byte tables' weights
     }
     out->rec.assign(n_slots, Trie8TRec{0, 0});
-    for (uint32_t t = 0; t < n_slots; t++) {
+    parallel_ranges(n_slots, 131072, [&](size_t ta, size_t tb) {
+    for (uint32_t t = (uint32_t)ta; t < (uint32_t)tb; t++) {
         Trie8TRec& q = out->rec[t];
         const bool used = t != 0 && ft.table[t].check != kNoParent;
         if (used) {
@@ -490,6 +511,7 @@ void build_trie8t(const FlatTrie& ft, const uint64_t* offs, const double* scores
             q.tok = 0;
         }
     }
+    });
     out->root_base = ft.inner[0] ? (ft.table[0].base & ~kTerminalBit) : kTrie8LeafBase;
     out->ok = true;
 }
