@@ -387,10 +387,9 @@ uint32_t grid_blocks(const tgx_model* m, uint64_t n_samples) {
 tgx_status ensure_value_ranks(tgx_model* m, const tgx_corpus* c) {
     if (m->values_ranked || !m->have_trie8 || !c->n_bytes) return TGX_OK;
     m->values_ranked = true;
-    if (m->n_values <= tgx::encode5_max_hot(false, 13, 3, 160u * 1024u)) return TGX_OK;  // (every value in LDS anyway)
-    if (const char* e = knob("TGX_VALUE_RANK")) {
-        if (strcmp(e, "model") == 0) return TGX_OK;  // keep build_trie8's order (measurements, tests)
-    }
+    const char* vr = knob("TGX_VALUE_RANK");  // "model": keep build_trie8's order; "counts": re-rank even when every value fits (measurements, tests)
+    if (vr && strcmp(vr, "model") == 0) return TGX_OK;
+    if (m->n_values <= tgx::encode5_max_hot(false, 13, 3, 160u * 1024u) && !(vr && strcmp(vr, "counts") == 0)) return TGX_OK;  // (every value in LDS anyway)
     tgx::HostPhases hp("ensure_value_ranks");
     HIP_TRY(hipSetDevice(m->device));
     const uint32_t nv = m->n_values, chunk = 65536u;
