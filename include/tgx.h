@@ -134,15 +134,17 @@ uint64_t tgx_utf8_lossy(const uint8_t *s, uint64_t n, uint8_t *out);
 /* ---- `generate`: document frequencies of substrings on the device (csrc/generate.hip) ----------------
  * VocabularyGenerator::feed (src/generate.rs:54-139): in how many samples does every char-aligned substring of
  * at most max_token_length (<= 32) bytes occur?  Parts are the byte ranges the windows may lie in (the samples,
- * or the matches of the split regex), sorted, disjoint, with ascending sample ids.  A (sample, substring) pair is
- * kept iff tgx_generate_u01(seed, sample, FNV-1a-64(substring)) < insert_probability (the reference draws from an
- * unseeded thread RNG).  Out: one entry per distinct substring — position and length of one occurrence, number
+ * or the matches of the split regex), sorted, disjoint, with ascending sample ids; part_origin[k] = where the part's
+ * sample begins in `text` (NULL: every part is a sample of its own).  Every OCCURRENCE is kept with probability
+ * insert_probability, as in the reference's loops (src/generate.rs:84-89, 108-113; a substring with k occurrences in a
+ * sample counts for it with probability 1 - (1 - p)^k): occurrence (sample, offset o in the sample, length l) is kept iff
+ * tgx_generate_u01(seed, sample, o << 8 | l) < insert_probability (the reference draws from an unseeded thread RNG).  Out: one entry per distinct substring — position and length of one occurrence, number
  * of samples — malloc'd (tgx_free).  Two different substrings in one 64-bit sort key are detected (every entry of a run is
  * compared with the run's first, byte by byte) and resolved: the pass is sorted again under a second, independent hash of
  * the windows' bytes (up to three times; *n_collisions = entries that had met a foreign run in the discarded attempts).
  * More than 2^32 - 1 kept windows in one call: TGX_ERR_UNSUPPORTED ("feed smaller batches"). */
 tgx_status tgx_substring_df(int device, const uint8_t *text, uint64_t n_bytes, const uint64_t *part_begin,
-                            const uint64_t *part_end, const uint32_t *part_sample, uint64_t n_parts,
+                            const uint64_t *part_end, const uint32_t *part_sample, const uint64_t *part_origin, uint64_t n_parts,
                             uint32_t max_token_length, double insert_probability, uint64_t seed,
                             uint64_t **out_pos, uint32_t **out_len, uint32_t **out_df, uint64_t *n_out,
                             uint64_t *n_windows, uint64_t *n_collisions);
@@ -152,7 +154,7 @@ tgx_status tgx_substring_df(int device, const uint8_t *text, uint64_t n_bytes, c
  * *n_distinct = distinct substrings counted; *cutoff_df = the frequency of the most frequent substring NOT
  * returned (0 when nothing was cut): whatever is missing from the output occurs in at most that many samples. */
 tgx_status tgx_substring_df_top(int device, const uint8_t *text, uint64_t n_bytes, const uint64_t *part_begin,
-                                const uint64_t *part_end, const uint32_t *part_sample, uint64_t n_parts,
+                                const uint64_t *part_end, const uint32_t *part_sample, const uint64_t *part_origin, uint64_t n_parts,
                                 uint32_t max_token_length, double insert_probability, uint64_t seed,
                                 uint64_t top_k, uint64_t **out_pos, uint32_t **out_len, uint32_t **out_df,
                                 uint64_t *n_out, uint64_t *n_windows, uint64_t *n_collisions,

@@ -8,8 +8,10 @@ or imported here (Rust / PyO3).
 
 Two forced differences from the reference, shared with the product so that both can be compared exactly:
   * `rng.gen_range(0.0..1.0) < insert_probability` draws from an unseeded thread RNG (src/generate.rs:88, 112, 126);
-    here a counter hash of (seed, sample index, FNV-1a-64 of the candidate's bytes) decides — the function
-    include/tgx.h documents as tgx_generate_u01 — so runs are reproducible;
+    here a counter hash of (seed, sample index, the occurrence: byte offset in the sample << 8 | byte length) decides —
+    the function include/tgx.h documents as tgx_generate_u01 — so runs are reproducible, with one draw per occurrence as
+    in the reference (round 4; one draw per (sample, substring) before: a substring occurring k times in a sample was
+    counted for it with probability p instead of 1 - (1 - p)^k);
   * `sort_unstable_by_key` / `sort_unstable_by` (src/generate.rs:152, 216-220) leave the order of equal frequencies /
     scores unspecified; ties are ordered by the token's bytes.
 """
@@ -27,10 +29,11 @@ def fnv1a64(data: bytes) -> int:
     return h
 
 
-def keep_u01(seed: int, sample: int, token: str) -> float:
-    """The seeded stand-in for the reference's thread RNG (tgx_generate_u01 of include/tgx.h)."""
-    h = fnv1a64(token.encode("utf-8", "surrogatepass"))
-    x = (seed ^ (sample * 0x9E3779B97F4A7C15) ^ (h * 0xC2B2AE3D27D4EB4F)) & _M64
+def keep_u01(seed: int, sample: int, occurrence: int) -> float:
+    """The seeded stand-in for the reference's thread RNG (tgx_generate_u01 of include/tgx.h): one draw per OCCURRENCE,
+    as the reference draws inside its loops over positions and lengths (src/generate.rs:84-89, 108-113, 122-127).
+    occurrence = byte offset in the sample << 8 | byte length (| 1 << 63 for the draws of the added / suggested tokens)."""
+    x = (seed ^ (sample * 0x9E3779B97F4A7C15) ^ ((occurrence & _M64) * 0xC2B2AE3D27D4EB4F)) & _M64
     x ^= x >> 30
     x = (x * 0xBF58476D1CE4E5B9) & _M64
     x ^= x >> 27
@@ -55,13 +58,16 @@ class OracleVocabularyGenerator:
         for t in self.added_tokens + self.suggested_tokens:  # src/generate.rs:33-41
             self.frequencies[t] = self.frequencies.get(t, 0) + 1
 
-    def _keep(self, sample_index: int, token: str) -> bool:
-        return self.insert_probability >= 1.0 or keep_u01(self.seed, sample_index, token) < self.insert_probability
+    def _keep(self, sample_index: int, offset: int, length: int, added: bool = False) -> bool:
+        occ = (offset << 8) | length | ((1 << 63) if added else 0)
+        return self.insert_probability >= 1.0 or keep_u01(self.seed, sample_index, occ) < self.insert_probability
 
-    def _candidates(self, part: str, sample_index: int, out: set):
-        """src/generate.rs:72-96 / 99-120: every char-aligned substring of at most max_token_length BYTES."""
+    def _candidates(self, part: str, part_offset: int, sample_index: int, out: set):
+        """src/generate.rs:72-96 / 99-120: every char-aligned substring of at most max_token_length BYTES, every
+        occurrence with a draw of its own.  part_offset: byte offset of the part in its sample."""
         n = len(part)
         blen = [len(c.encode("utf-8", "surrogatepass")) for c in part]
+        start = part_offset
         for i in range(n):
             total = 0
             for j in range(i, n):
@@ -69,8 +75,9 @@ class OracleVocabularyGenerator:
                 if total > self.max_token_length:
                     break
                 cand = part[i:j + 1]
-                if (self.allow is None or self.allow.search(cand)) and self._keep(sample_index, cand):
+                if (self.allow is None or self.allow.search(cand)) and self._keep(sample_index, start, total):
                     out.add(cand)
+            start += blen[i]
 
     def feed(self, samples: list[str]) -> None:
         """src/generate.rs:54-139: DOCUMENT frequencies — a sample's set of candidates counts once each."""
@@ -80,12 +87,18 @@ class OracleVocabularyGenerator:
             toks: set = set()
             if self.split is not None:
                 for m in self.split.finditer(sample):
-                    self._candidates(m.group(0), idx, toks)
+                    self._candidates(m.group(0), len(sample[:m.start()].encode("utf-8", "surrogatepass")), idx, toks)
             else:
-                self._candidates(sample, idx, toks)
-            for t in self.added_tokens + self.suggested_tokens:  # src/generate.rs:117-127
-                if t and t in sample and self._keep(idx, t):
-                    toks.add(t)
+                self._candidates(sample, 0, idx, toks)
+            for t in self.added_tokens + self.suggested_tokens:  # src/generate.rs:117-127: a draw per match, the first success inserts
+                if not t:
+                    continue
+                pos = sample.find(t)
+                while pos >= 0:  # str::match_indices: successive non-overlapping matches
+                    if self._keep(idx, len(sample[:pos].encode("utf-8", "surrogatepass")), len(t.encode("utf-8", "surrogatepass")), added=True):
+                        toks.add(t)
+                        break
+                    pos = sample.find(t, pos + len(t))
             for t in toks:
                 self.frequencies[t] = self.frequencies.get(t, 0) + 1
 

@@ -51,8 +51,24 @@ def test_keep_rule_is_the_librarys():
     """The seeded stand-in for the reference's thread RNG is one function in the oracle and in the library."""
     from tokengeex_amd import _lib
     assert fnv1a64(b"") == 0xCBF29CE484222325 and fnv1a64(b"a") == 0xAF63DC4C8601EC8C   # FNV-1a test vectors
-    for seed, sample, tok in [(0, 0, "a"), (7, 123456, "hello"), (2**63 + 5, 99, "中文"), (1, 2**26, " x")]:
-        assert keep_u01(seed, sample, tok) == _lib.generate_u01(seed, sample, fnv1a64(tok.encode()))
+    for seed, sample, occ in [(0, 0, 1), (7, 123456, (17 << 8) | 5), (2**63 + 5, 99, (1 << 63) | (3 << 8) | 6), (1, 2**26, (2**30 << 8) | 32)]:
+        assert keep_u01(seed, sample, occ) == _lib.generate_u01(seed, sample, occ)
+
+
+def test_one_draw_per_occurrence():
+    """src/generate.rs:84-89, 108-113, 122-127 draw inside the loops over positions, lengths and matches: a substring with k
+    occurrences in a sample is counted for it with probability 1 - (1 - p)^k, not p.  4 000 one-line samples with "ab"
+    eight times each and "xy" once: the counts follow those probabilities (binomial, 5 sigma)."""
+    p, n = 0.1, 4000
+    g = OracleVocabularyGenerator(2, p, None, None, ["ab"], [], seed=3)  # "ab" is an added token too: the draws of its matches add to the windows'
+    h = OracleVocabularyGenerator(2, p, None, None, seed=3)
+    samples = ["ab ab ab ab ab ab ab ab xy"] * n
+    g.feed(samples)
+    h.feed(samples)
+    def near(count, prob):
+        return abs(count - n * prob) <= 5.0 * (n * prob * (1.0 - prob)) ** 0.5
+    assert near(h.frequencies["xy"], p) and near(h.frequencies["ab"], 1.0 - (1.0 - p) ** 8)
+    assert near(g.frequencies["ab"] - 1, 1.0 - (1.0 - p) ** 16)  # (- 1: added tokens start at 1, src/generate.rs:33-41)
 
 
 def test_pass_sizing_keeps_a_device_pass_below_its_window_limit():

@@ -74,8 +74,8 @@ SYMBOLS = {
     "tgx_assemble_ids": (_i, [_vp, _vp, _u64, _vp, _vp, _u32, _vp, _vp]),
     "tgx_decode_batch": (_i, [_vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u64, _i, _pvp, _vp, _pu64, _pu64]),
     "tgx_utf8_lossy": (_u64, [_vp, _u64, _vp]),
-    "tgx_substring_df": (_i, [_i, _vp, _u64, _vp, _vp, _vp, _u64, _u32, _d, _u64, _pvp, _pvp, _pvp, _pu64, _pu64, _pu64]),
-    "tgx_substring_df_top": (_i, [_i, _vp, _u64, _vp, _vp, _vp, _u64, _u32, _d, _u64, _u64, _pvp, _pvp, _pvp, _pu64, _pu64, _pu64,
+    "tgx_substring_df": (_i, [_i, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _u32, _d, _u64, _pvp, _pvp, _pvp, _pu64, _pu64, _pu64]),
+    "tgx_substring_df_top": (_i, [_i, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _u32, _d, _u64, _u64, _pvp, _pvp, _pvp, _pu64, _pu64, _pu64,
                                   _pu64, C.POINTER(C.c_uint32)]),
     "tgx_generate_u01": (_d, [_u64, _u64, _u64]),
     "tgx_free": (None, [_vp]),
@@ -308,14 +308,17 @@ def decode_batch_flat(vocab_flat, vocab_offs, vocab_size: int, special_flat, spe
 
 
 def substring_df(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray, part_sample: np.ndarray,
-                 max_token_length: int, insert_probability: float = 1.0, seed: int = 0, device: int = 0, with_collisions: bool = False):
+                 max_token_length: int, insert_probability: float = 1.0, seed: int = 0, device: int = 0, with_collisions: bool = False,
+                 part_origin=None):
     """Document frequencies of char-aligned substrings on the device -> (pos u64[D], len u32[D], df u32[D], n_windows
-    [, entries that met a foreign run in a discarded attempt])."""
+    [, entries that met a foreign run in a discarded attempt]).  part_origin: where every part's sample begins in `flat`
+    (None: the part is its own sample) — the keep rule hashes the occurrence's offset in its sample."""
     flat = np.ascontiguousarray(flat, np.uint8)
     pb, pe = np.ascontiguousarray(part_begin, np.uint64), np.ascontiguousarray(part_end, np.uint64)
     ps = np.ascontiguousarray(part_sample, np.uint32)
+    po = None if part_origin is None else np.ascontiguousarray(part_origin, np.uint64)
     pos, ln, df, n, nw, nc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
-    check(lib.tgx_substring_df(device, ptr(flat) if flat.size else None, flat.size, ptr(pb), ptr(pe), ptr(ps), pb.shape[0],
+    check(lib.tgx_substring_df(device, ptr(flat) if flat.size else None, flat.size, ptr(pb), ptr(pe), ptr(ps), None if po is None else ptr(po), pb.shape[0],
                                max_token_length, float(insert_probability), seed & (2**64 - 1), C.byref(pos), C.byref(ln),
                                C.byref(df), C.byref(n), C.byref(nw), C.byref(nc)))
     k = n.value
@@ -324,15 +327,16 @@ def substring_df(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray,
 
 
 def substring_df_top(flat: np.ndarray, part_begin: np.ndarray, part_end: np.ndarray, part_sample: np.ndarray,
-                     max_token_length: int, top_k: int, insert_probability: float = 1.0, seed: int = 0, device: int = 0):
+                     max_token_length: int, top_k: int, insert_probability: float = 1.0, seed: int = 0, device: int = 0, part_origin=None):
     """The top_k most frequent substrings only (descending frequency; 0 = all)
     -> (pos, len, df, n_windows, n_distinct, cutoff_df): whatever was cut off occurs in at most cutoff_df samples."""
     flat = np.ascontiguousarray(flat, np.uint8)
     pb, pe = np.ascontiguousarray(part_begin, np.uint64), np.ascontiguousarray(part_end, np.uint64)
     ps = np.ascontiguousarray(part_sample, np.uint32)
+    po = None if part_origin is None else np.ascontiguousarray(part_origin, np.uint64)
     pos, ln, df, n, nw, nc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_uint64()
     nd, cut = C.c_uint64(), C.c_uint32()
-    check(lib.tgx_substring_df_top(device, ptr(flat) if flat.size else None, flat.size, ptr(pb), ptr(pe), ptr(ps), pb.shape[0],
+    check(lib.tgx_substring_df_top(device, ptr(flat) if flat.size else None, flat.size, ptr(pb), ptr(pe), ptr(ps), None if po is None else ptr(po), pb.shape[0],
                                    max_token_length, float(insert_probability), seed & (2**64 - 1), int(top_k), C.byref(pos),
                                    C.byref(ln), C.byref(df), C.byref(n), C.byref(nw), C.byref(nc), C.byref(nd), C.byref(cut)))
     k = n.value

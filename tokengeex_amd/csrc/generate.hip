@@ -56,6 +56,7 @@ struct WindowParams {
     const uint64_t* part_begin;   // parts (samples, or the split regex's matches) sorted, disjoint
     const uint64_t* part_end;
     const uint32_t* part_sample;
+    const uint64_t* part_origin;  // offset in `text` of the first byte of the part's SAMPLE (the keep rule hashes the window's offset in its sample)
     uint64_t n_parts;
     const uint32_t* blk_part;     // per block of 256 positions: first part whose end lies beyond the block's start
     uint32_t max_len;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void window_kernel(WindowParams P) {
     const uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t sample = 0;
+    uint64_t origin = 0;
     uint64_t end = 0;  // end of this position's part; 0 = the position starts no window
     if (p < P.n_bytes) {
         uint64_t k = P.blk_part[blockIdx.x];
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(256) void window_kernel(WindowParams P) {
         if (k < P.n_parts && P.part_begin[k] <= p && (P.text[p] & 0xC0u) != 0x80u) {  // inside a part, at a character start
             end = P.part_end[k];
             sample = P.part_sample[k];
+            origin = P.part_origin[k];
         }
     }
     // the windows of this position in ascending length; `emit` is called for the kept ones (src/generate.rs:99-120)
@@ -94,7 +97,9 @@ __global__ __launch_bounds__(256) void window_kernel(WindowParams P) {
             h = (h ^ c) * kFnvPrime;
             if (P.salt) g = ((g ^ c) * 0x9E3779B97F4A7C15ULL) ^ (g >> 29);  // an unrelated mixing chain: keys that met under h part here
             const bool boundary = (p + len == end) || (P.text[p + len] & 0xC0u) != 0x80u;
-            if (boundary && (P.prob >= 1.0 || generate_u01(P.seed, sample, h) < P.prob)) {  // (the keep rule always hashes h)
+            // one draw per OCCURRENCE (src/generate.rs:84-89, 108-113: `rng.gen_range(0.0..1.0) < insert_probability` inside the loops
+            // over positions and lengths): the stand-in for the thread RNG hashes (seed, sample, offset in the sample, length)
+            if (boundary && (P.prob >= 1.0 || generate_u01(P.seed, sample, ((p - origin) << 8) | len) < P.prob)) {
                 emit(kept, (P.salt ? g : h) & P.key_mask, len);
                 kept++;
             }
@@ -183,15 +188,17 @@ extern "C" {
 double tgx_generate_u01(uint64_t seed, uint64_t sample, uint64_t window_hash) { return tgx::generate_u01(seed, sample, window_hash); }
 
 // Document frequencies of the char-aligned substrings of at most max_token_length (<= 32) bytes of the parts
-// text[part_begin[k], part_end[k]) (sorted, disjoint; part_sample[k] non-decreasing), kept with probability
-// insert_probability per (sample, substring).  Out: one entry per distinct substring — the position and length
+// text[part_begin[k], part_end[k]) (sorted, disjoint; part_sample[k] non-decreasing), every OCCURRENCE kept with probability
+// insert_probability (src/generate.rs:84-89, 108-113: a substring with k occurrences in a sample is counted for it with
+// probability 1 - (1 - p)^k); part_origin[k]: where the part's sample begins in `text` (NULL: the part is its own sample) —
+// the draw of an occurrence is tgx_generate_u01(seed, sample, offset in the sample << 8 | length).  Out: one entry per distinct substring — the position and length
 // of one occurrence and the number of samples it occurs in — malloc'd (tgx_free), in ascending order of the
 // substrings' sort keys (their FNV-1a hashes).  Two different substrings with one 64-bit key are DETECTED (every entry of
 // a run is compared with the run's first, byte by byte) and resolved: the pass is sorted again under a second, salted hash
 // of the windows' bytes, up to three times; *n_collisions reports how many entries met a foreign run in the attempts that
 // were discarded.  text must be < 4 GiB.
 static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
-                                    const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
+                                    const uint64_t* part_end, const uint32_t* part_sample, const uint64_t* part_origin, uint64_t n_parts,
                                     uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t top_k,
                                     uint64_t** out_pos, uint32_t** out_len, uint32_t** out_df, uint64_t* n_out,
                                     uint64_t* n_windows, uint64_t* n_collisions, uint64_t* n_distinct, uint32_t* cutoff_df) {
@@ -211,6 +218,7 @@ static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_
     if (n_bytes >= (1ull << 32)) return tgx_set_error(TGX_ERR_UNSUPPORTED, "tgx_substring_df: feed at most 4 GiB per call");
     if (n_parts == 0 || n_bytes == 0) return TGX_OK;
     for (uint64_t k = 0; k < n_parts; k++) {
+        if (part_origin && part_origin[k] > part_begin[k]) return tgx_set_error(TGX_ERR_INVALID, "tgx_substring_df: a part begins before its sample");
         if (part_end[k] < part_begin[k] || part_end[k] > n_bytes || (k && part_begin[k] < part_end[k - 1]) ||
             (k && part_sample[k] < part_sample[k - 1]) || part_sample[k] >= (1u << 27))
             return tgx_set_error(TGX_ERR_INVALID, "tgx_substring_df: parts must be sorted, disjoint, inside the text, with ascending sample ids below 2^27");
@@ -266,6 +274,9 @@ static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_
     G_TRY(hipMemcpy(d_pb, part_begin, n_parts * 8, hipMemcpyHostToDevice));
     G_TRY(hipMemcpy(d_pe, part_end, n_parts * 8, hipMemcpyHostToDevice));
     G_TRY(hipMemcpy(d_ps, part_sample, n_parts * 4, hipMemcpyHostToDevice));
+    uint64_t* d_po = (uint64_t*)dalloc(n_parts * 8);
+    if (!d_po) return fail(TGX_ERR_DEVICE, "out of device memory (generate)");
+    G_TRY(hipMemcpy(d_po, part_origin ? part_origin : part_begin, n_parts * 8, hipMemcpyHostToDevice));
     G_TRY(hipMemcpy(d_bp, blk_part.data(), n_blocks * 4, hipMemcpyHostToDevice));
     G_TRY(hipMemset(d_ctr, 0, 64));
     WindowParams P{};
@@ -274,6 +285,7 @@ static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_
     P.part_begin = d_pb;
     P.part_end = d_pe;
     P.part_sample = d_ps;
+    P.part_origin = d_po;
     P.n_parts = n_parts;
     P.blk_part = d_bp;
     P.max_len = max_token_length;
@@ -420,11 +432,11 @@ static tgx_status substring_df_impl(int device, const uint8_t* text, uint64_t n_
 }
 
 tgx_status tgx_substring_df(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
-                            const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
+                            const uint64_t* part_end, const uint32_t* part_sample, const uint64_t* part_origin, uint64_t n_parts,
                             uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t** out_pos,
                             uint32_t** out_len, uint32_t** out_df, uint64_t* n_out, uint64_t* n_windows,
                             uint64_t* n_collisions) {
-    return substring_df_impl(device, text, n_bytes, part_begin, part_end, part_sample, n_parts, max_token_length,
+    return substring_df_impl(device, text, n_bytes, part_begin, part_end, part_sample, part_origin, n_parts, max_token_length,
                              insert_probability, seed, 0, out_pos, out_len, out_df, n_out, n_windows, n_collisions, nullptr, nullptr);
 }
 
@@ -433,11 +445,11 @@ tgx_status tgx_substring_df(int device, const uint8_t* text, uint64_t n_bytes, c
 // returned (0 when nothing was cut) — every substring that is not in the output occurs in at most that many
 // samples, which is what lets a caller that accumulates several calls decide whether its selection is exact.
 tgx_status tgx_substring_df_top(int device, const uint8_t* text, uint64_t n_bytes, const uint64_t* part_begin,
-                                const uint64_t* part_end, const uint32_t* part_sample, uint64_t n_parts,
+                                const uint64_t* part_end, const uint32_t* part_sample, const uint64_t* part_origin, uint64_t n_parts,
                                 uint32_t max_token_length, double insert_probability, uint64_t seed, uint64_t top_k,
                                 uint64_t** out_pos, uint32_t** out_len, uint32_t** out_df, uint64_t* n_out,
                                 uint64_t* n_windows, uint64_t* n_collisions, uint64_t* n_distinct, uint32_t* cutoff_df) {
-    return substring_df_impl(device, text, n_bytes, part_begin, part_end, part_sample, n_parts, max_token_length,
+    return substring_df_impl(device, text, n_bytes, part_begin, part_end, part_sample, part_origin, n_parts, max_token_length,
                              insert_probability, seed, top_k, out_pos, out_len, out_df, n_out, n_windows, n_collisions, n_distinct, cutoff_df);
 }
 

@@ -19,8 +19,9 @@ every pass reports the frequency of the first substring it cut, `generate` adds 
 passes, make it exact again.  With top_k = None everything is returned and nothing can be uncertain.
 
 Differences from the reference, both forced: the reference draws `rng.gen_range(0.0..1.0)` from an unseeded
-thread RNG for `insert_probability` (src/generate.rs:88,112,126), here a counter hash of (seed, sample,
-FNV-1a-64 of the candidate's bytes) decides — tgx_generate_u01, the same function on the device and in the
+thread RNG for `insert_probability` (src/generate.rs:88,112,126), here a counter hash of (seed, sample, the
+occurrence: byte offset in the sample << 8 | byte length) decides, one draw per occurrence as in the reference's
+loops — tgx_generate_u01, the same function on the device and in the
 CPU oracle — so runs are reproducible; tokens of equal frequency / score are ordered by their bytes
 (`sort_unstable_by` leaves their order unspecified).  The split regex (fancy_regex) is taken as a compiled Python
 pattern.
@@ -52,9 +53,10 @@ def _fnv1a64(data: bytes) -> int:
     return h
 
 
-def _u01(seed: int, sample: int, token: str) -> float:
-    """tgx_generate_u01(seed, sample, FNV-1a-64(token bytes)) — include/tgx.h, csrc/generate.hip."""
-    return _lib.generate_u01(seed, sample, _fnv1a64(token.encode("utf-8", "surrogatepass")))
+def _u01(seed: int, sample: int, offset: int, length: int, added: bool = False) -> float:
+    """tgx_generate_u01(seed, sample, occurrence) — include/tgx.h, csrc/generate.hip: the draw of ONE occurrence (byte
+    offset in the sample, byte length); `added`: the draws of the added / suggested tokens' matches (src/generate.rs:122-127)."""
+    return _lib.generate_u01(seed, sample, (offset << 8) | length | ((1 << 63) if added else 0))
 
 
 class VocabularyGenerator:
@@ -88,8 +90,28 @@ class VocabularyGenerator:
         for t in self.added_tokens + self.suggested_tokens:  # src/generate.rs:33-41
             self._freq[t] = self._freq.get(t, 0) + 1
 
-    def _keep(self, sample_index: int, token: str) -> bool:
-        return self.insert_probability >= 1.0 or _u01(self.seed, sample_index, token) < self.insert_probability
+    def _keep(self, sample_index: int, offset: int, length: int, added: bool = False) -> bool:
+        return self.insert_probability >= 1.0 or _u01(self.seed, sample_index, offset, length, added) < self.insert_probability
+
+    def _extra_kept(self, sample_index: int, sample: str, b: bytes, parts, t: str, tb: bytes) -> bool:
+        """Does sample's set hold the added / suggested token t (src/generate.rs:72-127)?  Either a window that spells it was
+        kept (every char-aligned occurrence inside a part is a candidate with a draw of its own, if the token is short enough
+        and allowed) or one of its successive non-overlapping matches was (str::match_indices, a draw per match)."""
+        if self.insert_probability >= 1.0:
+            return t in sample
+        if len(tb) <= self.max_token_length and (self.allow is None or self.allow.search(t)):
+            for a, z in parts:
+                o = b.find(tb, a, z)
+                while o >= 0:
+                    if (b[o] & 0xC0) != 0x80 and self._keep(sample_index, o, len(tb)):
+                        return True
+                    o = b.find(tb, o + 1, z)
+        o = b.find(tb)
+        while o >= 0:
+            if self._keep(sample_index, o, len(tb), added=True):
+                return True
+            o = b.find(tb, o + len(tb))
+        return False
 
     def feed(self, samples: list[str]) -> None:
         """feed(&mut self, samples) — src/generate.rs:54-139: DOCUMENT frequencies (one count per sample).
@@ -129,11 +151,14 @@ class VocabularyGenerator:
 
     def _count(self, samples: list[str], enc: list[bytes], first: int) -> None:
         flat, offs = _lib.pack(enc)
+        parts_of: list[list[tuple[int, int]]] = [[(0, len(b))] for b in enc]  # per sample: its parts as byte ranges in the sample
         if self.split is None:
             keep = np.flatnonzero(offs[1:] > offs[:-1])
             pb, pe, ps = offs[:-1][keep], offs[1:][keep], keep.astype(np.uint32)
+            po = pb
         else:  # the parts are the split regex's matches, as byte ranges (src/generate.rs:67-70)
             pb_l, pe_l, ps_l = [], [], []
+            parts_of = [[] for _ in enc]
             for i, (s, b) in enumerate(zip(samples, enc)):
                 if len(b) == len(s):  # ASCII: char offsets are byte offsets
                     spans = [mt.span() for mt in self.split.finditer(s)]
@@ -147,14 +172,17 @@ class VocabularyGenerator:
                         pb_l.append(base + a)
                         pe_l.append(base + z)
                         ps_l.append(i)
+                        parts_of[i].append((a, z))
                         last = z
             pb, pe, ps = np.array(pb_l, np.uint64), np.array(pe_l, np.uint64), np.array(ps_l, np.uint32)
+            po = offs[:-1][ps.astype(np.int64)] if ps.size else pb  # where every part's sample begins in the pass's buffer
         extra = self.added_tokens + self.suggested_tokens
         extra_set = set(extra)
         if pb.size:
             # the keep rule sees the global sample index (the device packs it into 27 bits)
             pos, ln, df, _, _, cut = _lib.substring_df_top(flat, pb, pe, (ps.astype(np.uint64) + first).astype(np.uint32),
-                                                           self.max_token_length, self.top_k, self.insert_probability, self.seed, self.device)
+                                                           self.max_token_length, self.top_k, self.insert_probability, self.seed, self.device,
+                                                           part_origin=po)
             self.passes += 1  # (counted once the device has answered: a refused batch is retried in halves)
             self._bound_total += cut
             raw = flat.tobytes()
@@ -166,13 +194,13 @@ class VocabularyGenerator:
                     self._freq[cand] = self._freq.get(cand, 0) + d_
                     if cut:
                         self._bound_seen[cand] = self._bound_seen.get(cand, 0) + cut
-        # added and suggested tokens: any occurrence in the sample counts (src/generate.rs:117-127).  The keep
-        # rule is a function of (seed, sample, token), so a window of the same text made the same decision and
-        # the union of both rules is this one.
+        # added and suggested tokens (src/generate.rs:117-127): counted here, sample by sample, with both rules that can put
+        # them into a sample's set (the device's counts of these strings are skipped above)
         for t in dict.fromkeys(extra):
             if not t:
                 continue
-            n = sum(1 for i, sample in enumerate(samples) if t in sample and self._keep(first + i, t))
+            tb = t.encode("utf-8", "surrogatepass")
+            n = sum(1 for i, sample in enumerate(samples) if t in sample and self._extra_kept(first + i, sample, enc[i], parts_of[i], t, tb))
             if n:
                 self._freq[t] = self._freq.get(t, 0) + n
 
