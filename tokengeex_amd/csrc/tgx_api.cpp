@@ -199,6 +199,7 @@ struct tgx_model {
     uint64_t last_long_samples = 0;    // samples the last pass gave a block of their own (encode6_kernel)
     uint64_t last_estep_pieces = 0;    // pieces the last E-step cut its snippets into (0: uncut)
     uint32_t last_corun_cus = 0;       // CUs the long-sample kernel had to itself beside encode5_kernel in the last pass (0: one after the other)
+    double e7_overflow_share = 0.0;    // share of the sample's matches whose token ranks beyond 65 535 (ensure_estep_trie8t; 0 without counts)
     bool values_ranked = false;        // the score values were re-ranked by how often a sample of some corpus reads them (ensure_value_ranks)
     uint32_t corun_wait_timeouts = 0;  // co-run passes whose host wait for encode5_kernel's blocks ran into its 2 ms limit (then: no more co-runs)
     uint64_t last_redo_samples = 0;    // samples the last encode4l pass left to encode2_kernel
@@ -2663,11 +2664,15 @@ static tgx_status ensure_estep_trie8t(tgx_model* m, const tgx_corpus* c) {
         std::vector<uint32_t> perm(nw, 0u);
         std::vector<double> w2(nw, 0.0);
         std::vector<uint32_t> id2(nw, tgx::kNoToken);
+        unsigned long long all_matches = 0, far_matches = 0;
         for (uint32_t r = 0; r < n_tok; r++) {
             perm[order[r]] = r + 1u;
             w2[r + 1u] = t8.w[order[r]];
             id2[r + 1u] = t8.id_of_rank[order[r]];
+            all_matches += cnt[order[r]];
+            if (r + 1u > 65535u) far_matches += cnt[order[r]];
         }
+        m->e7_overflow_share = all_matches ? (double)far_matches / (double)all_matches : 0.0;
         t8.w.swap(w2);
         t8.id_of_rank.swap(id2);
         if (hipMemcpyAsync(d_perm, perm.data(), nw * 4, hipMemcpyHostToDevice, m->stream) != hipSuccess ||
@@ -2740,7 +2745,8 @@ static tgx_status estep_fused(tgx_model* m, tgx_corpus* c, uint64_t snippet_len,
     // 65 535: the tokens are ranked by match counts) matches to the redo kernel, which has 32-bit entries then.
     // TGX_E7_OVF_AT=<rank> (tests) makes the ranks beyond <rank> such tokens.
     uint32_t ovf_limit = 0xFFFFFFFFu;
-    if (m->n_tok7 > 65535u && m->n_tok7 <= 65535u + 1024u) ovf_limit = 65535u;
+    // (only while those tokens are rare in the text: a trip holds ~150 matches, the redo kernel is several times slower per trip)
+    if (m->n_tok7 > 65535u && m->n_tok7 <= 65535u + 1024u && m->e7_overflow_share < 1e-4) ovf_limit = 65535u;
     if (const char* e = knob("TGX_E7_OVF_AT")) {
         const long v = atol(e);
         if (v >= 1 && v <= 65535 && m->n_tok7 <= 65535u + 1024u) ovf_limit = (uint32_t)v;
