@@ -45,7 +45,7 @@ for case in range(cases):
     dropout = float(rng.choice([0.0, 0.0, 0.1, 0.5, 1.0]))
     sd = int(rng.integers(0, 1 << 62))
     for k in ("TGX_PPL", "TGX_EPPL", "TGX_PATH", "TGX_LONG_THRESHOLD", "TGX_E5_HOT", "TGX_E6_POOL", "TGX_E2E_CHUNK_MB", "TGX_ESTEP_PIECES", "TGX_ESTEP_WINDOW", "TGX_CORUN",
-              "TGX_TRACE", "TGX_TRACE_CARRY", "TGX_E7_HOT", "TGX_E7_WAVES", "TGX_E7_RANK", "TGX_E7_OVF_AT", "TGX_ESTEP"):
+              "TGX_TRACE", "TGX_TRACE_CARRY", "TGX_E7_HOT", "TGX_E7_WAVES", "TGX_E7_RANK", "TGX_E7_OVF_AT", "TGX_ESTEP", "TGX_VALUE_RANK"):
         os.environ.pop(k, None)
     # round 4: the trace's two modes and the mask pipeline; estep7_kernel's table size, waves, rank order, overflow build;
     # the chained kernels now and then
@@ -56,6 +56,7 @@ for case in range(cases):
     if rng.random() < 0.3: os.environ["TGX_E7_RANK"] = "model"
     if rng.random() < 0.3: os.environ["TGX_E7_OVF_AT"] = str(int(rng.choice([3, 50, 400, 2000])))
     if rng.random() < 0.15: os.environ["TGX_ESTEP"] = "chain"
+    if rng.random() < 0.5: os.environ["TGX_VALUE_RANK"] = str(rng.choice(["counts", "model"]))  # encode5's values re-ranked by match counts
     if rng.random() < 0.6: os.environ["TGX_PPL"] = str(int(rng.choice([1, 2, 4])))
     if rng.random() < 0.6: os.environ["TGX_EPPL"] = str(int(rng.choice([1, 2, 4])))
     # round 2: kernel choice (encode5 / encode4), long-sample kernel threshold, score table size (cold values
