@@ -91,7 +91,12 @@ struct Res5 {
 // not exist — and the stagger would be lost; lanes reading record 0 cost the texture path next to nothing,
 // profiles/r03/d_gather3_dead_lanes.txt.  For the same reason the hottest slots are NOT read from an LDS copy:
 // tried, 2 % at best, a step still waits for its slowest lane, which goes to L2.)
-template <bool DROPOUT, bool LONG, bool RES, int PPL, int D>
+// SKIP (the COLD builds of encode5_kernel, round 4): from depth 11 on a walk whose lanes are all finished issues no
+// gather — 5 of a trip's 43 gathers have no live lane at all (the trip goes on while ANY of its walks is alive).  The
+// conditional load costs the stagger at those depths (see above), so the build with every value in LDS, whose vector and
+// texture units are in balance, loses (12.63 -> 13.07 ms per GiB); the COLD build, whose cold values go through the texture
+// path as well, gains (14.30 -> 13.70).  From depth 7 or 9 on it loses in both.
+template <bool DROPOUT, bool LONG, bool RES, int PPL, int D, bool SKIP = false>
 struct Walk5 {
     // rec[g], c[g]: record and text byte of depth D of walk g (the load may still be in flight)
     static __device__ __forceinline__ void run(const WalkCtx<PPL>& W, Res5& R, const uint32_t (&bytes)[PPL][4], const uint32_t (&maxd)[PPL],
@@ -131,7 +136,11 @@ struct Walk5 {
                 c[g] = (bytes[g][e >> 2] >> ((e & 3) * 8)) & 0xFFu;
                 alive[g] = alive[g] && ((uint32_t)e < maxd[g]);
                 const uint32_t off = (rec[g].x ^ (c[g] << 3)) & 0xFFFFFFu;
-                rec[g] = buf_ld8(W.trie, alive[g] ? off : 0u);
+                if (SKIP && D >= 11) {
+                    if (__builtin_amdgcn_ballot_w64(alive[g]) != 0) rec[g] = buf_ld8(W.trie, alive[g] ? off : 0u);
+                } else {
+                    rec[g] = buf_ld8(W.trie, alive[g] ? off : 0u);
+                }
             } else if (!LONG) {
                 alive[g] = false;
             }  // LONG: alive[g] says whether the walk goes on past 16 bytes (rec[g] is its record of depth 15): e5_long_tail
@@ -141,11 +150,11 @@ struct Walk5 {
             if (RES) R.complete();
             return;
         }
-        Walk5<DROPOUT, LONG, RES, PPL, D + 1>::run(W, R, bytes, maxd, pg, wlane, alive, rec, c);
+        Walk5<DROPOUT, LONG, RES, PPL, D + 1, SKIP>::run(W, R, bytes, maxd, pg, wlane, alive, rec, c);
     }
 };
-template <bool DROPOUT, bool LONG, bool RES, int PPL>
-struct Walk5<DROPOUT, LONG, RES, PPL, 16> {
+template <bool DROPOUT, bool LONG, bool RES, int PPL, bool SKIP>
+struct Walk5<DROPOUT, LONG, RES, PPL, 16, SKIP> {
     static __device__ __forceinline__ void run(const WalkCtx<PPL>&, Res5& R, const uint32_t (&)[PPL][4], const uint32_t (&)[PPL],
                                                const uint32_t (&)[PPL], const uint32_t (&)[PPL], bool (&)[PPL], uint2 (&)[PPL],
                                                uint32_t (&)[PPL]) {
@@ -431,7 +440,7 @@ __global__ __launch_bounds__(1024, (PPL == 1 ? 8 : (PPL == 2 ? 6 : (PPL == 3 ? 4
             asm volatile("" : "+v"(l32));
             WalkCtx<PPL> W{trie_b, s, l32, P.dropout, P.seed};
             Res5 no_res{};
-            Walk5<DROPOUT, LONG, false, PPL, 0>::run(W, no_res, bytes, maxd, pg, wlane, alive, rec, c);
+            Walk5<DROPOUT, LONG, false, PPL, 0, COLD && PPL < 4>::run(W, no_res, bytes, maxd, pg, wlane, alive, rec, c);  // (four positions per lane: the geometry of batches bound by their chains, where the stagger is worth more — 512 MiB 9.67 -> 10.11 ms with SKIP)
         }
         if (LONG) {
 #pragma unroll
